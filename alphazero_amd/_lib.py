@@ -1,0 +1,98 @@
+"""ctypes binding of libazhip.so (the HIP engine).  No fallback: if the library is
+missing or fails to load, importing the engine raises."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libazhip.so')
+
+GAME_TTT, GAME_C4 = 0, 1
+MAX_ACTIONS, MAX_MOVES = 9, 42
+NO_NODE = 0xFFFFFFFF
+LEAF_NONE, LEAF_EVAL, LEAF_TERMINAL, LEAF_ROOT = 0, 1, 2, 3
+WINNER_NONE, WINNER_DRAW = -2, -1
+
+
+class AzError(RuntimeError):
+    pass
+
+
+class EngineConfig(C.Structure):
+    _fields_ = [('game', C.c_int32), ('num_games', C.c_int32), ('node_capacity', C.c_int32),
+                ('num_simulations', C.c_int32), ('exploration_depth', C.c_int32),
+                ('reuse_search_tree', C.c_int32), ('device', C.c_int32), ('model_version', C.c_int32),
+                ('alpha', C.c_double), ('epsilon', C.c_double), ('c_base', C.c_double),
+                ('c_init', C.c_double), ('seed', C.c_uint64), ('first_game_uid', C.c_uint64),
+                ('uid_stride', C.c_uint64)]
+
+
+class GameRecord(C.Structure):
+    _fields_ = [('uid', C.c_uint64), ('num_moves', C.c_int32), ('winner', C.c_int32),
+                ('model_version', C.c_int32), ('reserved', C.c_int32),
+                ('history', C.c_uint8 * (MAX_MOVES + 6)), ('num_edges', C.c_uint8 * (MAX_MOVES + 6)),
+                ('visits', (C.c_uint32 * MAX_ACTIONS) * MAX_MOVES)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ('sims', 'select_steps', 'leaf_evals', 'root_evals', 'moves',
+                                          'games', 'errors')]
+
+
+# every symbol include/azhip.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SIGNATURES = {
+    'az_last_error': (C.c_char_p, []),
+    'az_version': (C.c_int, []),
+    'az_engine_create': (C.c_int, [C.POINTER(EngineConfig), C.POINTER(_P)]),
+    'az_engine_destroy': (C.c_int, [_P]),
+    'az_reset_games': (C.c_int, [_P, _P]),
+    'az_set_puct_lut': (C.c_int, [_P, _P, C.c_int32]),
+    'az_set_model_version': (C.c_int, [_P, C.c_int32]),
+    'az_begin_move': (C.c_int, [_P, _P, _P, _P]),
+    'az_apply_root': (C.c_int, [_P, _P, _P, _P]),
+    'az_select': (C.c_int, [_P, _P, _P, _P]),
+    'az_expand_backup': (C.c_int, [_P, _P, _P, _P]),
+    'az_sim_step': (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    'az_run_sims_uniform': (C.c_int, [_P, C.c_int32, _P]),
+    'az_begin_move_uniform': (C.c_int, [_P, _P, _P]),
+    'az_choose_and_advance': (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    'az_drain_finished': (C.c_int, [_P, C.POINTER(GameRecord), C.c_int32, C.POINTER(C.c_int32), _P]),
+    'az_get_stats': (C.c_int, [_P, C.POINTER(Stats), _P]),
+    'az_set_position': (C.c_int, [_P, C.c_int32, C.c_uint64, C.c_uint64, C.c_int32, _P, C.c_int32, C.c_uint32]),
+    'az_get_tree': (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]),
+    'az_node_words': (C.c_int, [_P]),
+    'az_positions_from_history': (C.c_int, [C.c_int32, _P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
+    'az_game_query': (C.c_int, [C.c_int32, _P, _P, C.c_int32, _P, _P, _P, _P]),
+    'az_game_step': (C.c_int, [C.c_int32, _P, _P, _P, C.c_int32, _P, _P]),
+    'az_render': (C.c_int, [C.c_int32, _P, C.c_int32, _P, _P, _P]),
+    'az_masked_softmax': (C.c_int, [C.c_int32, _P, _P, C.c_int32, _P, _P]),
+    'az_ucb_score': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libazhip.so; raises AzError when it is not built (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AzError(f'{LIB_PATH} not found: build it with `make -C alphazero_amd/csrc` '
+                      '(python -c "import __graft_entry__ as g; g.build()")')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise AzError(load().az_last_error().decode())
+
+
+def ptr(t):
+    """Device (or host) pointer of a torch tensor / None."""
+    return None if t is None else C.c_void_p(t.data_ptr())

@@ -1,0 +1,969 @@
+// az_engine.hip -- wavefront-per-tree PUCT self-play engine for gfx950 (MI355X).
+//
+// One 64-lane wavefront owns one game: its root position, its node pool and
+// its path stack.  Nothing is shared between games, so there are no atomics or
+// inter-workgroup hand-offs on the search path; parallelism is across games
+// only and each tree sees its simulations strictly in order, which is what
+// makes visit counts equal to the reference's (alphazero/mcts.py:110-158).
+//
+// Node = (A+1) records of 16 B: edge i = {N u32, W f32, P f32, child u32},
+// last record = {num_edges, sum N, -, -}.  For Connect Four that is one
+// 128-byte line: one HBM/L2 line per node visited during select.  Lane i loads
+// record i with a single dwordx4; PUCT scores are formed per lane in fp64 and
+// arg-maxed across the 8/16-lane row.
+//
+// Numerics are the reference's numpy-2 promotion (alphazero/mcts.py:43-59):
+//   Q = (float)((double)W/(double)N); U = (Cs*(double)P)*(sqrt(Ns)/(double)(1+N));
+//   score = (double)Q + U.  Cs and sqrt(Ns) come from a host table indexed by Ns.
+// The file is compiled with -ffp-contract=off: a fused multiply-add anywhere in
+// the score would change roundings and, eventually, visit counts.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <string>
+#include <vector>
+
+#include "../../include/azhip.h"
+#include "az_games.h"
+
+#define WAVES_PER_BLOCK 4
+#define BLOCK_THREADS (64 * WAVES_PER_BLOCK)
+#define PATH_LEN 48
+#define HIST_PAD (AZ_MAX_MOVES + 6)
+
+static thread_local std::string g_err;
+static int fail(const char* what, hipError_t e = hipSuccess) {
+    g_err = what;
+    if (e != hipSuccess) { g_err += ": "; g_err += hipGetErrorString(e); }
+    return -1;
+}
+#define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(#x, _e); } while (0)
+
+// ---------------------------------------------------------------------------
+// device-side state
+// ---------------------------------------------------------------------------
+struct __attribute__((aligned(128))) Slot {
+    uint64_t nx, pv;                 // root position
+    uint64_t uid;
+    uint64_t leaf_nx, leaf_pv;       // pending leaf position
+    uint64_t st_sims, st_steps, st_evals, st_root_evals, st_moves, st_games;
+    int32_t  nm;
+    uint32_t root;
+    uint32_t alloc;
+    int32_t  leaf_kind;
+    int32_t  leaf_depth;
+    int32_t  leaf_nm;
+    uint32_t err;
+    uint32_t move_sims;
+    uint32_t path[PATH_LEN];         // (node << 4) | slot per select level
+    uint8_t  hist[HIST_PAD];
+    uint8_t  nedges[HIST_PAD];
+};
+
+struct Dev {
+    uint4*          pool;       // [G][cap][A+1]
+    Slot*           slots;      // [G]
+    uint32_t*       rec_visits; // [G][AZ_MAX_MOVES][AZ_MAX_ACTIONS]
+    const double2*  lut;        // {Cs, sqrt(Ns)} by Ns
+    az_game_record* ring;
+    uint32_t*       ring_count;
+    uint32_t        ring_cap;
+    int32_t         lut_len;
+    int32_t         G, cap, S, explore_depth, reuse, version;
+    double          alpha, eps, c_base, c_init;
+    float           one_minus_eps;
+    uint64_t        seed, uid_stride, first_uid;
+};
+
+struct az_engine {
+    az_engine_config cfg;
+    Dev d;
+    int A;
+    double2* lut_dev;
+};
+
+// ---------------------------------------------------------------------------
+// wave helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ uint32_t uniu(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+// max over each row of 16 lanes (butterfly: xor 1, xor 2, half-row mirror, row mirror)
+__device__ __forceinline__ double row16_max(double x) {
+#if AZ_USE_SHFL
+    x = fmax(x, __shfl_xor(x, 1)); x = fmax(x, __shfl_xor(x, 2));
+    x = fmax(x, __shfl_xor(x, 4)); x = fmax(x, __shfl_xor(x, 8));
+#else
+    x = fmax(x, dpp_f64<0xB1>(x));   // quad_perm [1,0,3,2]
+    x = fmax(x, dpp_f64<0x4E>(x));   // quad_perm [2,3,0,1]
+    x = fmax(x, dpp_f64<0x141>(x));  // row_half_mirror
+    x = fmax(x, dpp_f64<0x140>(x));  // row_mirror
+#endif
+    return x;
+}
+__device__ __forceinline__ double row16_sum(double x) {
+    x += __shfl_xor(x, 1); x += __shfl_xor(x, 2); x += __shfl_xor(x, 4); x += __shfl_xor(x, 8);
+    return x;
+}
+
+// alphazero/mcts.py:43-59 for one edge
+__device__ __forceinline__ double puct_score(uint32_t N, float W, float P, double cs, double sq) {
+    const float Q = N ? (float)((double)W / (double)N) : 0.0f;
+    const double s = sq / (double)(N + 1u);
+    const double U = (cs * (double)P) * s;
+    return (double)Q + U;
+}
+
+__device__ __forceinline__ void lut_lookup(const Dev& E, uint32_t Ns, double& cs, double& sq) {
+    if ((int32_t)Ns < E.lut_len) {
+        const double2 t = E.lut[Ns];
+        cs = t.x; sq = t.y;
+    } else {  // beyond the host table: device libm (not bit-pinned to numpy)
+        cs = log((double)(1ull + Ns + (uint64_t)E.c_base) / E.c_base) + E.c_init;
+        sq = sqrt((double)Ns);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// counter-based RNG (Philox4x32-10) for production noise / move sampling
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                       uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {
+    return (double)((((uint64_t)hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0);
+}
+// two uniforms in [0,1) for (uid, move, purpose, attempt)
+__device__ __forceinline__ void rng2(const Dev& E, uint64_t uid, uint32_t move, uint32_t purpose,
+                                     uint32_t attempt, double& a, double& b) {
+    uint32_t o[4];
+    philox(attempt, (move << 8) | purpose, (uint32_t)uid, (uint32_t)(uid >> 32),
+           (uint32_t)E.seed, (uint32_t)(E.seed >> 32), o);
+    a = u53(o[0], o[1]); b = u53(o[2], o[3]);
+}
+// Gamma(alpha, 1) by Marsaglia-Tsang (alpha < 1 boosted); purpose = edge index
+__device__ double gamma_draw(const Dev& E, uint64_t uid, uint32_t move, uint32_t edge, double alpha) {
+    const double a = alpha < 1.0 ? alpha + 1.0 : alpha;
+    const double d = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    double g = d;
+    for (uint32_t t = 0; t < 64; ++t) {
+        double u1, u2, u3, u4;
+        rng2(E, uid, move, edge, 2 * t + 2, u1, u2);
+        rng2(E, uid, move, edge, 2 * t + 3, u3, u4);
+        const double x = sqrt(-2.0 * log(1.0 - u1)) * cos(6.283185307179586 * u2);
+        double v = 1.0 + c * x;
+        if (v <= 0.0) continue;
+        v = v * v * v;
+        const double uu = 1.0 - u3;   // in (0, 1]
+        if (uu < 1.0 - 0.0331 * x * x * x * x || log(uu) < 0.5 * x * x + d * (1.0 - v + log(v))) {
+            g = d * v;
+            break;
+        }
+    }
+    if (alpha < 1.0) {
+        double u1, u2;
+        rng2(E, uid, move, edge, 1, u1, u2);
+        g *= pow(1.0 - u1, 1.0 / alpha);
+    }
+    return g;
+}
+
+// ---------------------------------------------------------------------------
+// per-wave search primitives
+// ---------------------------------------------------------------------------
+struct Leaf {
+    int kind, depth, nm;
+    uint64_t nx, pv;
+    float v;
+};
+
+// mcts.py:119-134: descend from the root by first-argmax PUCT until a terminal
+// position or an edge without an expanded child.  Lane d keeps level d of the path.
+template <class GM>
+__device__ Leaf select_leaf(const Dev& E, const uint4* pool, uint32_t root, uint64_t nx, uint64_t pv,
+                            int nm, uint32_t& my_path, uint32_t& steps) {
+    constexpr int AS = GM::A + 1;
+    const int lane = lane_id();
+    Leaf L;
+    L.depth = 0; L.v = 0.0f; L.kind = AZ_LEAF_NONE;
+    uint32_t node = root;
+    if (GM::winner(nx, pv, nm) != AZ_W_NONE) {   // terminal root: the reference's loop body never runs
+        L.nx = nx; L.pv = pv; L.nm = nm;
+        return L;
+    }
+    for (;;) {
+        uint4 e = make_uint4(0u, 0u, 0u, AZ_NO_NODE);
+        if (lane < AS) e = pool[(size_t)node * AS + lane];
+        const int n_edges = (int)rdlane(e.x, AS - 1);
+        const uint32_t Ns = rdlane(e.y, AS - 1);
+        double cs, sq;
+        lut_lookup(E, Ns, cs, sq);
+        const bool act = lane < n_edges;
+        double score = -INFINITY;
+        if (act) score = puct_score(e.x, __uint_as_float(e.y), __uint_as_float(e.z), cs, sq);
+        const double mx = row16_max(score);
+        const unsigned long long hit = __ballot(act && score == mx);
+        const int slot = uni(__ffsll((long long)hit) - 1);            // np.argmax: first maximum
+        const uint32_t child = rdlane(e.w, slot);
+        const int action = az_nth_set_bit(GM::legal(nx, pv), slot);    // mcts.py:126
+        if (lane == L.depth) my_path = (node << 4) | (uint32_t)slot;
+        L.depth += 1;
+        steps += 1;
+        GM::play(nx, pv, nm, action);
+        const int w = GM::winner(nx, pv, nm);
+        if (w != AZ_W_NONE) {                                          // mcts.py:131-134
+            L.kind = AZ_LEAF_TERMINAL;
+            L.v = az_terminal_value_prev(w, nm);
+            break;
+        }
+        if (child == AZ_NO_NODE) { L.kind = AZ_LEAF_EVAL; break; }    // mcts.py:135-138
+        node = child;
+    }
+    L.nx = nx; L.pv = pv; L.nm = nm;
+    return L;
+}
+
+// mcts.py:20-26: one new node; priors compacted to the legal moves in ascending
+// action order.  p == nullptr gives the UniformModel prior 1/n (models.py:90-95).
+template <class GM>
+__device__ uint32_t expand_node(const Dev& E, uint4* pool, uint32_t& alloc, uint64_t nx, uint64_t pv,
+                                const float* p, uint32_t& err) {
+    constexpr int AS = GM::A + 1;
+    const int lane = lane_id();
+    if (alloc >= (uint32_t)E.cap) { err |= 1u; return AZ_NO_NODE; }
+    const uint32_t idx = alloc;
+    alloc += 1;
+    const uint32_t legal = GM::legal(nx, pv);
+    const int n_edges = az_popc32(legal);
+    if (lane < AS) {
+        uint4 rec = make_uint4(0u, 0u, 0u, AZ_NO_NODE);
+        if (lane < n_edges) {
+            const int a = az_nth_set_bit(legal, lane);
+            const float pr = p ? p[a] : 1.0f / (float)n_edges;
+            rec.z = __float_as_uint(pr);
+        }
+        if (lane == AS - 1) rec = make_uint4((uint32_t)n_edges, 0u, 0u, 0u);
+        pool[(size_t)idx * AS + lane] = rec;
+    }
+    return idx;
+}
+
+// mcts.py:147-158: every level of the path in parallel (levels are distinct nodes)
+template <class GM>
+__device__ void backup_path(uint4* pool, int depth, uint32_t my_path, float v_leaf_edge) {
+    constexpr int AS = GM::A + 1;
+    const int lane = lane_id();
+    if (lane < depth) {
+        const uint32_t node = my_path >> 4, slot = my_path & 15u;
+        const float v = ((depth - 1 - lane) & 1) ? -v_leaf_edge : v_leaf_edge;
+        uint2* ep = reinterpret_cast<uint2*>(&pool[(size_t)node * AS + slot]);
+        uint2 nw = *ep;
+        nw.x += 1u;                                                   // mcts.py:86
+        nw.y = __float_as_uint(__uint_as_float(nw.y) + v);            // mcts.py:85 (fp32)
+        *ep = nw;
+        uint32_t* ns = reinterpret_cast<uint32_t*>(&pool[(size_t)node * AS + AS - 1]) + 1;
+        *ns += 1u;
+    }
+}
+
+// mcts.py:88-91
+template <class GM>
+__device__ void root_noise(const Dev& E, uint4* pool, uint32_t root, const double* eta_g, uint64_t uid,
+                           int move) {
+    constexpr int AS = GM::A + 1;
+    const int lane = lane_id();
+    const int n_edges = (int)pool[(size_t)root * AS + AS - 1].x;
+    double eta = 0.0;
+    if (eta_g) {
+        if (lane < n_edges) eta = eta_g[lane];
+    } else {
+        double g = 0.0;
+        if (lane < n_edges) g = gamma_draw(E, uid, (uint32_t)move, (uint32_t)lane, E.alpha);
+        const double s = row16_sum(g);
+        eta = s > 0.0 ? g / s : 1.0 / (double)n_edges;
+    }
+    if (lane < n_edges) {
+        uint32_t* pp = reinterpret_cast<uint32_t*>(&pool[(size_t)root * AS + lane]) + 2;
+        const float a = E.one_minus_eps * __uint_as_float(*pp);
+        *pp = __float_as_uint((float)((double)a + E.eps * eta));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// kernels: one wave per game
+// ---------------------------------------------------------------------------
+#define WAVE_PROLOGUE                                                                   \
+    const int g = uni((int)(blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)));       \
+    if (g >= E.G) return;                                                               \
+    const int lane = lane_id();                                                         \
+    Slot* s = E.slots + g;                                                              \
+    uint4* pool = E.pool + (size_t)g * E.cap * (GM::A + 1);                             \
+    (void)lane; (void)pool;
+
+template <class GM>
+__global__ void __launch_bounds__(BLOCK_THREADS) k_reset(Dev E) {
+    WAVE_PROLOGUE
+    if (lane == 0) {
+        s->nx = 0; s->pv = 0; s->nm = 0;
+        s->uid = E.first_uid + (uint64_t)g;
+        s->root = AZ_NO_NODE; s->alloc = 0;
+        s->leaf_kind = AZ_LEAF_NONE; s->leaf_depth = 0; s->leaf_nm = 0; s->leaf_nx = 0; s->leaf_pv = 0;
+        s->err = 0; s->move_sims = 0;
+        s->st_sims = s->st_steps = s->st_evals = s->st_root_evals = s->st_moves = s->st_games = 0;
+    }
+}
+
+// mcts.py:114-117.  UNIFORM: expand with 1/n in place and add the noise here.
+template <class GM, bool UNIFORM>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+k_begin_move(Dev E, uint64_t* leaf_bb, int32_t* leaf_info, const double* eta) {
+    WAVE_PROLOGUE
+    uint32_t root = s->root, alloc = s->alloc, err = s->err;
+    const uint64_t nx = s->nx, pv = s->pv;
+    const int nm = s->nm;
+    const bool need = (root == AZ_NO_NODE) && GM::winner(nx, pv, nm) == AZ_W_NONE;
+    if (UNIFORM) {
+        if (need) {
+            root = expand_node<GM>(E, pool, alloc, nx, pv, nullptr, err);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        }
+        if (root != AZ_NO_NODE)
+            root_noise<GM>(E, pool, root, eta ? eta + (size_t)g * GM::A : nullptr, s->uid, nm);
+        if (lane == 0) {
+            s->root = root; s->alloc = alloc; s->err = err; s->move_sims = 0;
+            s->leaf_kind = AZ_LEAF_NONE;
+            if (need) s->st_root_evals += 1;
+        }
+    } else {
+        if (lane == 0) {
+            s->leaf_kind = need ? AZ_LEAF_ROOT : AZ_LEAF_NONE;
+            s->leaf_depth = 0; s->leaf_nx = nx; s->leaf_pv = pv; s->leaf_nm = nm;
+            leaf_bb[2 * (size_t)g] = nx; leaf_bb[2 * (size_t)g + 1] = pv;
+            leaf_info[g] = (need ? AZ_LEAF_ROOT : AZ_LEAF_NONE) | (nm << 8) | ((int)GM::legal(nx, pv) << 16);
+        }
+    }
+}
+
+template <class GM>
+__global__ void __launch_bounds__(BLOCK_THREADS) k_apply_root(Dev E, const float* p, const double* eta) {
+    WAVE_PROLOGUE
+    uint32_t root = s->root, alloc = s->alloc, err = s->err;
+    const bool need = s->leaf_kind == AZ_LEAF_ROOT;
+    if (need) {
+        root = expand_node<GM>(E, pool, alloc, s->nx, s->pv, p + (size_t)g * GM::A, err);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
+    if (root != AZ_NO_NODE)
+        root_noise<GM>(E, pool, root, eta ? eta + (size_t)g * GM::A : nullptr, s->uid, s->nm);
+    if (lane == 0) {
+        s->root = root; s->alloc = alloc; s->err = err; s->move_sims = 0;
+        s->leaf_kind = AZ_LEAF_NONE;
+        if (need) s->st_root_evals += 1;
+    }
+}
+
+// mcts.py:119-158, one simulation per game per launch:
+//   DO_EXPAND: finish the pending simulation with the evaluator's (p, v);
+//   DO_SELECT: start the next one; terminal leaves are backed up at once.
+template <class GM, bool DO_EXPAND, bool DO_SELECT>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+k_sim_step(Dev E, const float* p, const float* v, uint64_t* leaf_bb, int32_t* leaf_info) {
+    WAVE_PROLOGUE
+    uint32_t alloc = s->alloc, err = s->err;
+    const uint32_t root = s->root;
+    uint32_t sims = 0, evals = 0, steps = 0;
+    int kind = s->leaf_kind;
+
+    if (DO_EXPAND && kind == AZ_LEAF_EVAL) {
+        const int depth = s->leaf_depth;
+        const uint32_t my_path = lane < depth ? s->path[lane] : 0u;
+        const uint32_t idx = expand_node<GM>(E, pool, alloc, s->leaf_nx, s->leaf_pv, p + (size_t)g * GM::A, err);
+        const uint32_t last = rdlane(my_path, depth - 1);
+        if (idx != AZ_NO_NODE && lane == 0)
+            reinterpret_cast<uint32_t*>(&pool[(size_t)(last >> 4) * (GM::A + 1) + (last & 15u)])[3] = idx;
+        backup_path<GM>(pool, depth, my_path, -v[g]);                  // mcts.py:144
+        sims += 1; evals += 1;
+        kind = AZ_LEAF_NONE;
+        if (DO_SELECT) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
+
+    if (DO_SELECT) {
+        Leaf L;
+        L.kind = AZ_LEAF_NONE; L.depth = 0; L.nx = s->nx; L.pv = s->pv; L.nm = s->nm; L.v = 0.f;
+        uint32_t my_path = 0;
+        if (root != AZ_NO_NODE) L = select_leaf<GM>(E, pool, root, s->nx, s->pv, s->nm, my_path, steps);
+        if (L.kind == AZ_LEAF_TERMINAL) {
+            backup_path<GM>(pool, L.depth, my_path, L.v);
+            sims += 1;
+        } else if (L.kind == AZ_LEAF_EVAL) {
+            if (lane < L.depth) s->path[lane] = my_path;
+        }
+        kind = L.kind;
+        if (lane == 0) {
+            s->leaf_depth = L.depth; s->leaf_nx = L.nx; s->leaf_pv = L.pv; s->leaf_nm = L.nm;
+            leaf_bb[2 * (size_t)g] = L.nx; leaf_bb[2 * (size_t)g + 1] = L.pv;
+            leaf_info[g] = L.kind | (L.nm << 8) | ((int)GM::legal(L.nx, L.pv) << 16);
+        }
+    }
+    if (lane == 0) {
+        s->leaf_kind = kind; s->alloc = alloc; s->err = err;
+        s->move_sims += sims; s->st_sims += sims; s->st_evals += evals; s->st_steps += steps;
+    }
+}
+
+// num_sims whole simulations per game in one launch, UniformModel evaluated in place
+template <class GM>
+__global__ void __launch_bounds__(BLOCK_THREADS) k_run_uniform(Dev E, int num_sims) {
+    WAVE_PROLOGUE
+    uint32_t alloc = s->alloc, err = s->err;
+    const uint32_t root = s->root;
+    const uint64_t nx = s->nx, pv = s->pv;
+    const int nm = s->nm;
+    uint32_t sims = 0, evals = 0, steps = 0;
+    if (root == AZ_NO_NODE) return;
+    for (int it = 0; it < num_sims; ++it) {
+        uint32_t my_path = 0;
+        const Leaf L = select_leaf<GM>(E, pool, root, nx, pv, nm, my_path, steps);
+        if (L.kind == AZ_LEAF_EVAL) {
+            const uint32_t idx = expand_node<GM>(E, pool, alloc, L.nx, L.pv, nullptr, err);
+            const uint32_t last = rdlane(my_path, L.depth - 1);
+            if (idx != AZ_NO_NODE && lane == 0)
+                reinterpret_cast<uint32_t*>(&pool[(size_t)(last >> 4) * (GM::A + 1) + (last & 15u)])[3] = idx;
+            backup_path<GM>(pool, L.depth, my_path, -0.0f);            // v = 0, then v *= -1
+            evals += 1;
+        } else if (L.kind == AZ_LEAF_TERMINAL) {
+            backup_path<GM>(pool, L.depth, my_path, L.v);
+        }
+        sims += 1;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // own stores before next select's loads
+    }
+    if (lane == 0) {
+        s->alloc = alloc; s->err = err; s->leaf_kind = AZ_LEAF_NONE;
+        s->move_sims += sims; s->st_sims += sims; s->st_evals += evals; s->st_steps += steps;
+    }
+}
+
+// selfplay.py:26-38 (+ :41 for finished games)
+template <class GM>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+k_choose(Dev E, const double* u_in, int32_t* out_action, int32_t* out_nedges, uint32_t* out_visits,
+         int32_t* out_winner) {
+    WAVE_PROLOGUE
+    constexpr int AS = GM::A + 1;
+    const uint32_t root = s->root;
+    uint64_t nx = s->nx, pv = s->pv;
+    int nm = s->nm;
+    if (root == AZ_NO_NODE) {   // nothing searched (terminal or never begun): report and leave
+        if (lane == 0) {
+            if (out_action) out_action[g] = -1;
+            if (out_nedges) out_nedges[g] = 0;
+            if (out_winner) out_winner[g] = GM::winner(nx, pv, nm);
+        }
+        if (out_visits && lane < GM::A) out_visits[(size_t)g * GM::A + lane] = 0;
+        return;
+    }
+    uint4 e = make_uint4(0u, 0u, 0u, AZ_NO_NODE);
+    if (lane < AS) e = pool[(size_t)root * AS + lane];
+    const int n_edges = (int)rdlane(e.x, AS - 1);
+    const uint32_t N = lane < n_edges ? e.x : 0u;
+
+    int slot;
+    if (nm < E.explore_depth) {
+        // mcts.py:61-71: pi = N/sum (fp64), legacy RandomState.choice = cdf search
+        double u;
+        if (u_in) u = u_in[g];
+        else { double t; rng2(E, s->uid, (uint32_t)nm, 0xFFu, 0, u, t); }
+        double ssum = 0.0;
+        for (int i = 0; i < n_edges; ++i) ssum += (double)rdlane(N, i);
+        double cdf[AZ_MAX_ACTIONS];
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < GM::A; ++i) {
+            if (i < n_edges) {
+                const double pi = ssum > 0.0 ? (double)rdlane(N, i) / ssum : 1.0 / (double)n_edges;
+                acc += pi;
+            }
+            cdf[i] = acc;
+        }
+        const double last = acc;
+        int idx = 0;
+#pragma unroll
+        for (int i = 0; i < GM::A; ++i)
+            if (i < n_edges && cdf[i] / last <= u) idx = i + 1;
+        slot = idx < n_edges ? idx : n_edges - 1;
+    } else {
+        // mcts.py:73-74: first maximum of N
+        uint32_t best = rdlane(N, 0);
+        slot = 0;
+        for (int i = 1; i < n_edges; ++i) {
+            const uint32_t ni = rdlane(N, i);
+            if (ni > best) { best = ni; slot = i; }
+        }
+    }
+    slot = uni(slot);
+    const int action = az_nth_set_bit(GM::legal(nx, pv), slot);
+    const uint32_t child = rdlane(e.w, slot);
+
+    // selfplay.py:31: search statistics of this move
+    if (lane < AZ_MAX_ACTIONS)
+        E.rec_visits[((size_t)g * AZ_MAX_MOVES + nm) * AZ_MAX_ACTIONS + lane] = N;
+    if (out_visits && lane < GM::A) out_visits[(size_t)g * GM::A + lane] = N;
+    if (lane == 0) {
+        s->hist[nm] = (uint8_t)action;
+        s->nedges[nm] = (uint8_t)n_edges;
+        if (out_action) out_action[g] = action;
+        if (out_nedges) out_nedges[g] = n_edges;
+    }
+    GM::play(nx, pv, nm, action);
+    const int w = GM::winner(nx, pv, nm);
+    if (lane == 0 && out_winner) out_winner[g] = w;
+
+    if (w != AZ_W_NONE) {
+        // selfplay.py:41: hand the finished game over, then restart the slot (selfplay.py:13-14)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        uint32_t pos = 0;
+        if (lane == 0) pos = atomicAdd(E.ring_count, 1u);
+        pos = uniu(pos);
+        if (pos < E.ring_cap) {
+            az_game_record* r = E.ring + pos;
+            if (lane == 0) {
+                r->uid = s->uid; r->num_moves = nm; r->winner = w; r->model_version = E.version; r->reserved = 0;
+            }
+            if (lane < HIST_PAD) { r->history[lane] = s->hist[lane]; r->num_edges[lane] = s->nedges[lane]; }
+            const uint32_t* src = E.rec_visits + (size_t)g * AZ_MAX_MOVES * AZ_MAX_ACTIONS;
+            uint32_t* dst = &r->visits[0][0];
+            for (int i = lane; i < AZ_MAX_MOVES * AZ_MAX_ACTIONS; i += 64)
+                dst[i] = (i < nm * AZ_MAX_ACTIONS) ? src[i] : 0u;
+        }
+        if (lane == 0) {
+            if (pos >= E.ring_cap) s->err |= 2u;
+            s->nx = 0; s->pv = 0; s->nm = 0; s->root = AZ_NO_NODE; s->alloc = 0;
+            s->uid += E.uid_stride;
+            s->st_moves += 1; s->st_games += 1; s->leaf_kind = AZ_LEAF_NONE; s->move_sims = 0;
+        }
+    } else if (lane == 0) {
+        s->nx = nx; s->pv = pv; s->nm = nm;
+        if (E.reuse) s->root = child;                       // selfplay.py:35-36
+        else { s->root = AZ_NO_NODE; s->alloc = 0; }        // selfplay.py:38
+        s->st_moves += 1; s->leaf_kind = AZ_LEAF_NONE; s->move_sims = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// stateless bulk kernels (one thread per position)
+// ---------------------------------------------------------------------------
+template <class GM>
+__global__ void k_from_history(const uint8_t* hist, const int32_t* len, int stride, int n, uint64_t* bb,
+                               int32_t* num_moves) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t nx = 0, pv = 0;
+    int nm = 0;
+    const int L = len[i];
+    for (int k = 0; k < L; ++k) GM::play(nx, pv, nm, hist[(size_t)i * stride + k]);
+    bb[2 * (size_t)i] = nx; bb[2 * (size_t)i + 1] = pv;
+    num_moves[i] = nm;
+}
+
+template <class GM>
+__global__ void k_query(const uint64_t* bb, const int32_t* num_moves, int n, int32_t* legal, int32_t* term,
+                        int32_t* winner) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t nx = bb[2 * (size_t)i], pv = bb[2 * (size_t)i + 1];
+    const int nm = num_moves[i];
+    const int w = GM::winner(nx, pv, nm);
+    if (legal) legal[i] = (int32_t)GM::legal(nx, pv);
+    if (term) term[i] = w != AZ_W_NONE;
+    if (winner) winner[i] = w;
+}
+
+template <class GM>
+__global__ void k_step(uint64_t* bb, int32_t* num_moves, const int32_t* action, int n, int32_t* status) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t nx = bb[2 * (size_t)i], pv = bb[2 * (size_t)i + 1];
+    int nm = num_moves[i];
+    const int a = action[i];
+    const bool ok = a >= 0 && a < GM::A && ((GM::legal(nx, pv) >> a) & 1u);   // game.py:31
+    if (ok) {
+        GM::play(nx, pv, nm, a);
+        bb[2 * (size_t)i] = nx; bb[2 * (size_t)i + 1] = pv;
+        num_moves[i] = nm;
+    }
+    if (status) status[i] = ok ? 0 : -1;
+}
+
+template <class GM>
+__global__ void k_render(const uint64_t* bb, int n, float* x, uint8_t* valid) {
+    constexpr int CELLS = GM::H * GM::W;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = t / (2 * CELLS), r = t % (2 * CELLS);
+    if (i >= n) return;
+    const uint64_t b = bb[2 * (size_t)i + r / CELLS];
+    const int c = r % CELLS;
+    if (x) x[t] = GM::cell(b, c / GM::W, c % GM::W) ? 1.0f : 0.0f;
+    if (valid && r < GM::A)
+        valid[(size_t)i * GM::A + r] = (GM::legal(bb[2 * (size_t)i], bb[2 * (size_t)i + 1]) >> r) & 1u;
+}
+
+template <int A>
+__global__ void k_masked_softmax(const float* logits, const int32_t* info, int n, float* p) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t legal = ((uint32_t)info[i] >> 16) & 0x1FFu;
+    float m = -INFINITY;
+    for (int a = 0; a < A; ++a) if ((legal >> a) & 1u) m = fmaxf(m, logits[(size_t)i * A + a]);
+    float e[A], sum = 0.f;
+    for (int a = 0; a < A; ++a) {
+        e[a] = ((legal >> a) & 1u) ? expf(logits[(size_t)i * A + a] - m) : 0.f;
+        sum += e[a];
+    }
+    for (int a = 0; a < A; ++a) p[(size_t)i * A + a] = ((legal >> a) & 1u) ? e[a] / sum : 0.f;
+}
+
+template <int A>
+__global__ void k_ucb(Dev E, const uint32_t* N, const float* W, const float* P, const int32_t* ne, int n,
+                      double* score, int32_t* argmax) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t Ns = 0;
+    const int k = ne[i];
+    for (int a = 0; a < k; ++a) Ns += N[(size_t)i * A + a];
+    double cs, sq;
+    lut_lookup(E, Ns, cs, sq);
+    int best = 0;
+    double bs = 0;
+    for (int a = 0; a < k; ++a) {
+        const double sc = puct_score(N[(size_t)i * A + a], W[(size_t)i * A + a], P[(size_t)i * A + a], cs, sq);
+        score[(size_t)i * A + a] = sc;
+        if (a == 0 || sc > bs) { bs = sc; best = a; }
+    }
+    for (int a = k; a < A; ++a) score[(size_t)i * A + a] = 0.0;
+    argmax[i] = best;
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static inline dim3 wave_grid(int G) { return dim3((G + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK); }
+#define LAUNCH_CHECK() do { hipError_t _e = hipGetLastError(); if (_e != hipSuccess) return fail("kernel launch", _e); } while (0)
+#define DISPATCH_GAME(game, ...)                                   \
+    do {                                                           \
+        if ((game) == AZ_GAME_C4) { using GM = GameC4; __VA_ARGS__; } \
+        else if ((game) == AZ_GAME_TTT) { using GM = GameTTT; __VA_ARGS__; } \
+        else return fail("unknown game id");                       \
+    } while (0)
+
+extern "C" {
+
+const char* az_last_error(void) { return g_err.c_str(); }
+int az_version(void) { return 1; }
+
+int az_engine_create(const az_engine_config* cfg, az_engine** out) {
+    if (!cfg || !out) return fail("null argument");
+    if (cfg->game != AZ_GAME_C4 && cfg->game != AZ_GAME_TTT) return fail("unknown game id");
+    if (cfg->num_games <= 0) return fail("num_games must be positive");
+    if (cfg->num_simulations < 0) return fail("num_simulations must be >= 0");
+    HIPCHK(hipSetDevice(cfg->device));
+    az_engine* e = new az_engine();
+    e->cfg = *cfg;
+    e->A = cfg->game == AZ_GAME_C4 ? GameC4::A : GameTTT::A;
+    const int lmax = cfg->game == AZ_GAME_C4 ? GameC4::LMAX : GameTTT::LMAX;
+    long cap = cfg->node_capacity;
+    if (cap <= 0) cap = cfg->reuse_search_tree ? (long)cfg->num_simulations * lmax + lmax + 1
+                                               : (long)cfg->num_simulations + 2;
+    if (cap >= (1l << 28)) { delete e; return fail("node_capacity too large"); }
+    Dev& d = e->d;
+    memset(&d, 0, sizeof(d));
+    d.G = cfg->num_games; d.cap = (int)cap; d.S = cfg->num_simulations;
+    d.explore_depth = cfg->exploration_depth; d.reuse = cfg->reuse_search_tree; d.version = cfg->model_version;
+    d.alpha = cfg->alpha; d.eps = cfg->epsilon; d.c_base = cfg->c_base; d.c_init = cfg->c_init;
+    d.one_minus_eps = (float)(1.0 - cfg->epsilon);
+    d.seed = cfg->seed; d.first_uid = cfg->first_game_uid;
+    d.uid_stride = cfg->uid_stride ? cfg->uid_stride : (uint64_t)cfg->num_games;
+    d.ring_cap = 2u * (uint32_t)cfg->num_games + 16u;
+    const size_t pool_bytes = (size_t)d.G * d.cap * (e->A + 1) * sizeof(uint4);
+    hipError_t err;
+    if ((err = hipMalloc(&d.pool, pool_bytes)) != hipSuccess ||
+        (err = hipMalloc(&d.slots, (size_t)d.G * sizeof(Slot))) != hipSuccess ||
+        (err = hipMalloc(&d.rec_visits, (size_t)d.G * AZ_MAX_MOVES * AZ_MAX_ACTIONS * 4)) != hipSuccess ||
+        (err = hipMalloc(&d.ring, (size_t)d.ring_cap * sizeof(az_game_record))) != hipSuccess ||
+        (err = hipMalloc(&d.ring_count, 256)) != hipSuccess) {
+        az_engine_destroy(e);
+        return fail("hipMalloc (node pools)", err);
+    }
+    HIPCHK(hipMemset(d.slots, 0, (size_t)d.G * sizeof(Slot)));
+    HIPCHK(hipMemset(d.rec_visits, 0, (size_t)d.G * AZ_MAX_MOVES * AZ_MAX_ACTIONS * 4));
+    HIPCHK(hipMemset(d.ring_count, 0, 256));
+    *out = e;
+    int rc = az_reset_games(e, nullptr);
+    if (rc) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    return 0;
+}
+
+int az_engine_destroy(az_engine* e) {
+    if (!e) return 0;
+    (void)hipSetDevice(e->cfg.device);
+    (void)hipFree(e->d.pool); (void)hipFree(e->d.slots); (void)hipFree(e->d.rec_visits); (void)hipFree(e->d.ring);
+    (void)hipFree(e->d.ring_count); (void)hipFree(e->lut_dev);
+    delete e;
+    return 0;
+}
+
+int az_reset_games(az_engine* e, void* stream) {
+    if (!e) return fail("null engine");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemsetAsync(e->d.ring_count, 0, 256, st));
+    DISPATCH_GAME(e->cfg.game, hipLaunchKernelGGL((k_reset<GM>), wave_grid(e->d.G), dim3(BLOCK_THREADS), 0, st, e->d));
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int az_set_puct_lut(az_engine* e, const double* lut_host, int32_t n) {
+    if (!e || !lut_host || n <= 0) return fail("bad PUCT table");
+    double2* dev = nullptr;
+    HIPCHK(hipMalloc(&dev, (size_t)n * sizeof(double2)));
+    HIPCHK(hipMemcpy(dev, lut_host, (size_t)n * sizeof(double2), hipMemcpyHostToDevice));
+    HIPCHK(hipDeviceSynchronize());
+    (void)hipFree(e->lut_dev);
+    e->lut_dev = dev; e->d.lut = dev; e->d.lut_len = n;
+    return 0;
+}
+
+int az_set_model_version(az_engine* e, int32_t version) {
+    if (!e) return fail("null engine");
+    e->d.version = version; e->cfg.model_version = version;
+    return 0;
+}
+
+int az_begin_move(az_engine* e, uint64_t* leaf_bb, int32_t* leaf_info, void* stream) {
+    if (!e || !leaf_bb || !leaf_info) return fail("null argument");
+    DISPATCH_GAME(e->cfg.game, hipLaunchKernelGGL((k_begin_move<GM, false>), wave_grid(e->d.G), dim3(BLOCK_THREADS), 0,
+                                                  (hipStream_t)stream, e->d, leaf_bb, leaf_info, (const double*)nullptr));
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int az_begin_move_uniform(az_engine* e, const double* eta, void* stream) {
+    if (!e) return fail("null engine");
+    DISPATCH_GAME(e->cfg.game, hipLaunchKernelGGL((k_begin_move<GM, true>), wave_grid(e->d.G), dim3(BLOCK_THREADS), 0,
+                                                  (hipStream_t)stream, e->d, (uint64_t*)nullptr, (int32_t*)nullptr, eta));
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int az_apply_root(az_engine* e, const float* p, const double* eta, void* stream) {
+    if (!e || !p) return fail("null argument");
+    DISPATCH_GAME(e->cfg.game, hipLaunchKernelGGL((k_apply_root<GM>), wave_grid(e->d.G), dim3(BLOCK_THREADS), 0,
+                                                  (hipStream_t)stream, e->d, p, eta));
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int az_select(az_engine* e, uint64_t* leaf_bb, int32_t* leaf_info, void* stream) {
+    if (!e || !leaf_bb || !leaf_info) return fail("null argument");
+    DISPATCH_GAME(e->cfg.game, hipLaunchKernelGGL((k_sim_step<GM, false, true>), wave_grid(e->d.G), dim3(BLOCK_THREADS), 0,
+                                                  (hipStream_t)stream, e->d, (const float*)nullptr, (const float*)nullptr,
+                                                  leaf_bb, leaf_info));
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int az_expand_backup(az_engine* e, const float* p, const float* v, void* stream) {
+    if (!e || !p || !v) return fail("null argument");
+    DISPATCH_GAME(e->cfg.game, hipLaunchKernelGGL((k_sim_step<GM, true, false>), wave_grid(e->d.G), dim3(BLOCK_THREADS), 0,
+                                                  (hipStream_t)stream, e->d, p, v, (uint64_t*)nullptr, (int32_t*)nullptr));
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int az_sim_step(az_engine* e, const float* p, const float* v, uint64_t* leaf_bb, int32_t* leaf_info, void* stream) {
+    if (!e || !leaf_bb || !leaf_info) return fail("null argument");
+    if (!p) return az_select(e, leaf_bb, leaf_info, stream);
+    if (!v) return fail("v is required with p");
+    DISPATCH_GAME(e->cfg.game, hipLaunchKernelGGL((k_sim_step<GM, true, true>), wave_grid(e->d.G), dim3(BLOCK_THREADS), 0,
+                                                  (hipStream_t)stream, e->d, p, v, leaf_bb, leaf_info));
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int az_run_sims_uniform(az_engine* e, int32_t num_sims, void* stream) {
+    if (!e || num_sims < 0) return fail("bad argument");
+    DISPATCH_GAME(e->cfg.game, hipLaunchKernelGGL((k_run_uniform<GM>), wave_grid(e->d.G), dim3(BLOCK_THREADS), 0,
+                                                  (hipStream_t)stream, e->d, (int)num_sims));
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int az_choose_and_advance(az_engine* e, const double* u, int32_t* action, int32_t* num_edges, uint32_t* visits,
+                          int32_t* winner, void* stream) {
+    if (!e) return fail("null engine");
+    DISPATCH_GAME(e->cfg.game, hipLaunchKernelGGL((k_choose<GM>), wave_grid(e->d.G), dim3(BLOCK_THREADS), 0,
+                                                  (hipStream_t)stream, e->d, u, action, num_edges, visits, winner));
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int az_drain_finished(az_engine* e, az_game_record* out_host, int32_t max_records, int32_t* num_out, void* stream) {
+    if (!e || !num_out) return fail("null argument");
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t count = 0;
+    HIPCHK(hipMemcpyAsync(&count, e->d.ring_count, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (count > e->d.ring_cap) count = e->d.ring_cap;
+    if ((int32_t)count > max_records) return fail("az_drain_finished: output buffer too small");
+    if (count && !out_host) return fail("null output buffer");
+    if (count) HIPCHK(hipMemcpyAsync(out_host, e->d.ring, (size_t)count * sizeof(az_game_record), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemsetAsync(e->d.ring_count, 0, 4, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *num_out = (int32_t)count;
+    return 0;
+}
+
+int az_get_stats(az_engine* e, az_stats* out, void* stream) {
+    if (!e || !out) return fail("null argument");
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<Slot> h((size_t)e->d.G);
+    HIPCHK(hipMemcpyAsync(h.data(), e->d.slots, h.size() * sizeof(Slot), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    memset(out, 0, sizeof(*out));
+    for (const Slot& s : h) {
+        out->sims += s.st_sims; out->select_steps += s.st_steps; out->leaf_evals += s.st_evals;
+        out->root_evals += s.st_root_evals; out->moves += s.st_moves; out->games += s.st_games;
+        out->errors += s.err ? 1 : 0;
+    }
+    return 0;
+}
+
+int az_node_words(const az_engine* e) { return e ? 4 * (e->A + 1) : 0; }
+
+int az_set_position(az_engine* e, int32_t g, uint64_t bb_next, uint64_t bb_prev, int32_t num_moves,
+                    const uint32_t* nodes_host, int32_t num_nodes, uint32_t root_node) {
+    if (!e || g < 0 || g >= e->d.G) return fail("bad game slot");
+    if (num_nodes < 0 || num_nodes > e->d.cap) return fail("tree larger than node_capacity");
+    if (root_node != AZ_NO_NODE && root_node >= (uint32_t)num_nodes) return fail("root_node out of range");
+    HIPCHK(hipDeviceSynchronize());
+    Slot s;
+    HIPCHK(hipMemcpy(&s, e->d.slots + g, sizeof(Slot), hipMemcpyDeviceToHost));
+    s.nx = bb_next; s.pv = bb_prev; s.nm = num_moves; s.root = root_node; s.alloc = (uint32_t)num_nodes;
+    s.leaf_kind = AZ_LEAF_NONE; s.leaf_depth = 0; s.move_sims = 0; s.err = 0;
+    HIPCHK(hipMemcpy(e->d.slots + g, &s, sizeof(Slot), hipMemcpyHostToDevice));
+    const size_t node_bytes = (size_t)(e->A + 1) * sizeof(uint4);
+    if (num_nodes) {
+        if (!nodes_host) return fail("null node image");
+        // child indices must stay inside the image
+        const int words = 4 * (e->A + 1);
+        for (int n = 0; n < num_nodes; ++n) {
+            const uint32_t ne = nodes_host[(size_t)n * words + 4 * e->A];
+            if (ne > (uint32_t)e->A) return fail("node image: num_edges out of range");
+            for (uint32_t i = 0; i < ne; ++i) {
+                const uint32_t c = nodes_host[(size_t)n * words + 4 * i + 3];
+                if (c != AZ_NO_NODE && c >= (uint32_t)num_nodes) return fail("node image: child out of range");
+            }
+        }
+        HIPCHK(hipMemcpy((char*)e->d.pool + (size_t)g * e->d.cap * node_bytes, nodes_host, (size_t)num_nodes * node_bytes,
+                         hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+int az_get_tree(az_engine* e, int32_t g, uint32_t* nodes_host, int32_t max_nodes, int32_t* num_nodes,
+                uint32_t* root_node) {
+    if (!e || g < 0 || g >= e->d.G || !num_nodes || !root_node) return fail("bad argument");
+    HIPCHK(hipDeviceSynchronize());
+    Slot s;
+    HIPCHK(hipMemcpy(&s, e->d.slots + g, sizeof(Slot), hipMemcpyDeviceToHost));
+    *num_nodes = (int32_t)s.alloc; *root_node = s.root;
+    if (!nodes_host) return 0;
+    if ((int32_t)s.alloc > max_nodes) return fail("az_get_tree: buffer too small");
+    const size_t node_bytes = (size_t)(e->A + 1) * sizeof(uint4);
+    if (s.alloc)
+        HIPCHK(hipMemcpy(nodes_host, (char*)e->d.pool + (size_t)g * e->d.cap * node_bytes, (size_t)s.alloc * node_bytes,
+                         hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- stateless bulk kernels -------------------------------------------------
+int az_positions_from_history(int32_t game, const uint8_t* hist, const int32_t* len, int32_t stride, int32_t n,
+                              uint64_t* bb, int32_t* num_moves, void* stream) {
+    if (n < 0 || (n && (!hist || !len || !bb || !num_moves))) return fail("bad argument");
+    if (n == 0) return 0;
+    DISPATCH_GAME(game, hipLaunchKernelGGL((k_from_history<GM>), dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                                           hist, len, (int)stride, (int)n, bb, num_moves));
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int az_game_query(int32_t game, const uint64_t* bb, const int32_t* num_moves, int32_t n, int32_t* legal_mask,
+                  int32_t* terminal, int32_t* winner, void* stream) {
+    if (n < 0 || (n && (!bb || !num_moves))) return fail("bad argument");
+    if (n == 0) return 0;
+    DISPATCH_GAME(game, hipLaunchKernelGGL((k_query<GM>), dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, bb,
+                                           num_moves, (int)n, legal_mask, terminal, winner));
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int az_game_step(int32_t game, uint64_t* bb, int32_t* num_moves, const int32_t* action, int32_t n, int32_t* status,
+                 void* stream) {
+    if (n < 0 || (n && (!bb || !num_moves || !action))) return fail("bad argument");
+    if (n == 0) return 0;
+    DISPATCH_GAME(game, hipLaunchKernelGGL((k_step<GM>), dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, bb,
+                                           num_moves, action, (int)n, status));
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int az_render(int32_t game, const uint64_t* bb, int32_t n, float* x, uint8_t* valid, void* stream) {
+    if (n < 0 || (n && !bb)) return fail("bad argument");
+    if (n == 0) return 0;
+    DISPATCH_GAME(game, {
+        const long total = (long)n * 2 * GM::H * GM::W;
+        hipLaunchKernelGGL((k_render<GM>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, bb,
+                           (int)n, x, valid);
+    });
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int az_masked_softmax(int32_t game, const float* logits, const int32_t* leaf_info, int32_t n, float* p, void* stream) {
+    if (n < 0 || (n && (!logits || !leaf_info || !p))) return fail("bad argument");
+    if (n == 0) return 0;
+    DISPATCH_GAME(game, hipLaunchKernelGGL((k_masked_softmax<GM::A>), dim3((n + 255) / 256), dim3(256), 0,
+                                           (hipStream_t)stream, logits, leaf_info, (int)n, p));
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int az_ucb_score(az_engine* e, const uint32_t* N, const float* W, const float* P, const int32_t* num_edges, int32_t n,
+                 double* score, int32_t* argmax, void* stream) {
+    if (!e || n < 0 || (n && (!N || !W || !P || !num_edges || !score || !argmax))) return fail("bad argument");
+    if (n == 0) return 0;
+    DISPATCH_GAME(e->cfg.game, hipLaunchKernelGGL((k_ucb<GM::A>), dim3((n + 255) / 256), dim3(256), 0,
+                                                  (hipStream_t)stream, e->d, N, W, P, num_edges, (int)n, score, argmax));
+    LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,231 @@
+"""SelfPlayEngine: Python handle on one az_engine (include/azhip.h).
+
+Owns the I/O tensors (torch, on the engine's device) and exposes each C-ABI entry
+point as a method.  All work is stream-ordered on torch's current stream.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (AzError, EngineConfig, GameRecord, Stats, LEAF_EVAL, LEAF_NONE, LEAF_ROOT,
+                   LEAF_TERMINAL, NO_NODE, check, ptr)
+
+GAME_SHAPES = {_lib.GAME_TTT: (9, 3, 3, 9), _lib.GAME_C4: (7, 6, 7, 42)}   # A, H, W, max moves
+
+
+def make_puct_lut(n, c_base=19652, c_init=1.25):
+    """float64 [n,2] table {Cs, sqrt(Ns)} for Ns = 0..n-1.
+
+    The two expressions are the reference's own (alphazero/mcts.py:55-57), evaluated
+    by the host's numpy on uint64 scalars, so the engine uses exactly the log the
+    reference would have computed on this machine."""
+    ns = np.arange(n, dtype=np.uint64)
+    cs = np.log((1 + ns + c_base) / c_base) + c_init
+    return np.ascontiguousarray(np.stack([cs, np.sqrt(ns)], axis=1), dtype=np.float64)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class SelfPlayEngine:
+    def __init__(self, game, num_games, num_simulations, exploration_depth=0, reuse_search_tree=True,
+                 alpha=0.3, epsilon=0.25, c_base=19652, c_init=1.25, seed=0, device=0,
+                 node_capacity=0, model_version=0, first_game_uid=0, uid_stride=0, lut=None):
+        if not torch.cuda.is_available():
+            raise AzError('SelfPlayEngine needs a GPU: there is no CPU path in this package')
+        self.lib = _lib.load()
+        self.game = int(game)
+        self.A, self.H, self.W, self.max_moves = GAME_SHAPES[self.game]
+        self.G = int(num_games)
+        self.S = int(num_simulations)
+        self.device = torch.device('cuda', device)
+        self.cfg = EngineConfig(self.game, self.G, int(node_capacity), self.S, int(exploration_depth),
+                                int(bool(reuse_search_tree)), int(device), int(model_version),
+                                float(alpha), float(epsilon), float(c_base), float(c_init),
+                                int(seed), int(first_game_uid), int(uid_stride))
+        h = C.c_void_p()
+        check(self.lib.az_engine_create(C.byref(self.cfg), C.byref(h)))
+        self.h = h
+        if lut is None:
+            reach = self.S * (self.max_moves if reuse_search_tree else 1) + 2
+            lut = make_puct_lut(max(reach, 1024), c_base, c_init)
+        self.set_puct_lut(lut)
+        with torch.cuda.device(self.device):
+            self.leaf_bb = torch.zeros(self.G, 2, dtype=torch.int64, device=self.device)
+            self.leaf_info = torch.zeros(self.G, dtype=torch.int32, device=self.device)
+            self.out_action = torch.zeros(self.G, dtype=torch.int32, device=self.device)
+            self.out_nedges = torch.zeros(self.G, dtype=torch.int32, device=self.device)
+            self.out_visits = torch.zeros(self.G, self.A, dtype=torch.int32, device=self.device)
+            self.out_winner = torch.zeros(self.G, dtype=torch.int32, device=self.device)
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.az_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- configuration ---------------------------------------------------------
+    def set_puct_lut(self, lut):
+        lut = np.ascontiguousarray(lut, dtype=np.float64)
+        assert lut.ndim == 2 and lut.shape[1] == 2
+        check(self.lib.az_set_puct_lut(self.h, C.c_void_p(lut.ctypes.data), lut.shape[0]))
+
+    def set_model_version(self, v):
+        check(self.lib.az_set_model_version(self.h, int(v)))
+
+    def reset_games(self):
+        check(self.lib.az_reset_games(self.h, _stream()))
+
+    # ---- one move, lock-step ---------------------------------------------------
+    def begin_move(self):
+        check(self.lib.az_begin_move(self.h, ptr(self.leaf_bb), ptr(self.leaf_info), _stream()))
+        return self.leaf_bb, self.leaf_info
+
+    def apply_root(self, p, eta=None):
+        assert p.dtype == torch.float32 and p.is_contiguous() and p.shape == (self.G, self.A)
+        if eta is not None:
+            assert eta.dtype == torch.float64 and eta.is_contiguous() and eta.shape == (self.G, self.A)
+        check(self.lib.az_apply_root(self.h, ptr(p), ptr(eta), _stream()))
+
+    def begin_move_uniform(self, eta=None):
+        if eta is not None:
+            assert eta.dtype == torch.float64 and eta.is_contiguous() and eta.shape == (self.G, self.A)
+        check(self.lib.az_begin_move_uniform(self.h, ptr(eta), _stream()))
+
+    def select(self):
+        check(self.lib.az_select(self.h, ptr(self.leaf_bb), ptr(self.leaf_info), _stream()))
+        return self.leaf_bb, self.leaf_info
+
+    def _check_pv(self, p, v):
+        assert p.dtype == torch.float32 and p.is_contiguous() and p.shape == (self.G, self.A)
+        assert v.dtype == torch.float32 and v.is_contiguous() and v.numel() == self.G
+
+    def expand_backup(self, p, v):
+        self._check_pv(p, v)
+        check(self.lib.az_expand_backup(self.h, ptr(p), ptr(v), _stream()))
+
+    def sim_step(self, p=None, v=None):
+        if p is not None:
+            self._check_pv(p, v)
+        check(self.lib.az_sim_step(self.h, ptr(p), ptr(v), ptr(self.leaf_bb), ptr(self.leaf_info), _stream()))
+        return self.leaf_bb, self.leaf_info
+
+    def run_sims_uniform(self, num_sims):
+        check(self.lib.az_run_sims_uniform(self.h, int(num_sims), _stream()))
+
+    def choose_and_advance(self, u=None):
+        if u is not None:
+            assert u.dtype == torch.float64 and u.is_contiguous() and u.numel() == self.G
+        check(self.lib.az_choose_and_advance(self.h, ptr(u), ptr(self.out_action), ptr(self.out_nedges),
+                                             ptr(self.out_visits), ptr(self.out_winner), _stream()))
+        return self.out_action, self.out_nedges, self.out_visits, self.out_winner
+
+    # ---- results -----------------------------------------------------------------
+    def drain_finished(self):
+        """Finished games since the last drain as a list of GameRecord (synchronises)."""
+        cap = 2 * self.G + 16
+        buf = (GameRecord * cap)()
+        n = C.c_int32()
+        check(self.lib.az_drain_finished(self.h, buf, cap, C.byref(n), _stream()))
+        return [buf[i] for i in range(n.value)]
+
+    def stats(self):
+        st = Stats()
+        check(self.lib.az_get_stats(self.h, C.byref(st), _stream()))
+        return {k: int(getattr(st, k)) for k, _ in Stats._fields_}
+
+    # ---- tree transfer (single-game mirror) -------------------------------------------
+    @property
+    def node_words(self):
+        return 4 * (self.A + 1)
+
+    def set_position(self, g, bb_next, bb_prev, num_moves, nodes=None, root_node=NO_NODE):
+        torch.cuda.synchronize(self.device)
+        if nodes is None or len(nodes) == 0:
+            check(self.lib.az_set_position(self.h, g, bb_next, bb_prev, num_moves, None, 0, NO_NODE))
+            return
+        nodes = np.ascontiguousarray(nodes, dtype=np.uint32).reshape(-1, self.node_words)
+        check(self.lib.az_set_position(self.h, g, bb_next, bb_prev, num_moves,
+                                       C.c_void_p(nodes.ctypes.data), nodes.shape[0], int(root_node)))
+
+    def get_tree(self, g):
+        """(uint32 [n, A+1, 4] node image, root index) of game slot g."""
+        torch.cuda.synchronize(self.device)
+        n, root = C.c_int32(), C.c_uint32()
+        check(self.lib.az_get_tree(self.h, g, None, 0, C.byref(n), C.byref(root)))
+        nodes = np.zeros((max(n.value, 1), self.node_words), np.uint32)
+        check(self.lib.az_get_tree(self.h, g, C.c_void_p(nodes.ctypes.data), nodes.shape[0],
+                                   C.byref(n), C.byref(root)))
+        return nodes[:n.value].reshape(n.value, self.A + 1, 4), int(root.value)
+
+
+# ---- stateless bulk game kernels ---------------------------------------------------
+def positions_from_history(game, histories, device='cuda'):
+    """List of action lists -> (bb int64[n,2], num_moves int32[n]) on the device."""
+    lib = _lib.load()
+    n = len(histories)
+    stride = max([len(h) for h in histories] + [1])
+    hist = np.zeros((n, stride), np.uint8)
+    lens = np.zeros(n, np.int32)
+    for i, h in enumerate(histories):
+        hist[i, :len(h)] = h
+        lens[i] = len(h)
+    dh = torch.from_numpy(hist).to(device)
+    dl = torch.from_numpy(lens).to(device)
+    bb = torch.zeros(n, 2, dtype=torch.int64, device=device)
+    nm = torch.zeros(n, dtype=torch.int32, device=device)
+    check(lib.az_positions_from_history(game, ptr(dh), ptr(dl), stride, n, ptr(bb), ptr(nm), _stream()))
+    return bb, nm
+
+
+def game_query(game, bb, nm):
+    lib = _lib.load()
+    n = bb.shape[0]
+    legal = torch.zeros(n, dtype=torch.int32, device=bb.device)
+    term = torch.zeros_like(legal)
+    win = torch.zeros_like(legal)
+    check(lib.az_game_query(game, ptr(bb), ptr(nm), n, ptr(legal), ptr(term), ptr(win), _stream()))
+    return legal, term, win
+
+
+def game_step(game, bb, nm, action):
+    lib = _lib.load()
+    n = bb.shape[0]
+    status = torch.zeros(n, dtype=torch.int32, device=bb.device)
+    check(lib.az_game_step(game, ptr(bb), ptr(nm), ptr(action), n, ptr(status), _stream()))
+    return status
+
+
+def render(game, bb):
+    """Network input planes x float32[n,2,H,W] and legal mask bool[n,A] for positions bb."""
+    lib = _lib.load()
+    A, H, W, _ = GAME_SHAPES[game]
+    n = bb.shape[0]
+    x = torch.empty(n, 2, H, W, dtype=torch.float32, device=bb.device)
+    valid = torch.empty(n, A, dtype=torch.uint8, device=bb.device)
+    check(lib.az_render(game, ptr(bb), n, ptr(x), ptr(valid), _stream()))
+    return x, valid.bool()
+
+
+def masked_softmax(game, logits, leaf_info):
+    lib = _lib.load()
+    logits = logits.contiguous().float()
+    p = torch.empty_like(logits)
+    check(lib.az_masked_softmax(game, ptr(logits), ptr(leaf_info), logits.shape[0], ptr(p), _stream()))
+    return p
+
+
+def leaf_kind(leaf_info):
+    return leaf_info & 0xFF
+
+
+def leaf_legal(leaf_info):
+    return (leaf_info >> 16) & 0x1FF

@@ -1,0 +1,68 @@
+"""Tic-tac-toe (interface of alphazero/games/tictactoe.py:9-72); squares 0..8 row-major."""
+import numpy as np
+
+from ..game import Game
+
+_LINES = (0o007, 0o070, 0o700, 0o111, 0o222, 0o444, 0o421, 0o124)
+
+
+def _line(b):
+    return any((b & m) == m for m in _LINES)
+
+
+class TicTacToe(Game):
+    NUM_ACTIONS = 9
+    AZ_GAME_ID = 0
+    BOARD_SHAPE = (3, 3)
+
+    def position(self, turn=None):
+        hist = self.history if turn is None else self.history[:turn]
+        nx = pv = 0
+        for a in hist:
+            nx, pv = pv, nx | (1 << a)
+        return nx, pv, len(hist)
+
+    @property
+    def valid_actions(self):
+        nx, pv, _ = self.position()
+        return [a for a in range(9) if not ((nx | pv) >> a) & 1]
+
+    @property
+    def winner(self):
+        n = len(self.history)
+        if n < 5:
+            return None
+        nx, pv, _ = self.position()
+        p0, p1 = (pv, nx) if n & 1 else (nx, pv)
+        if _line(p0):                      # player 0's lines are looked at first
+            return 0
+        if _line(p1):
+            return 1
+        if n == 9:
+            return -1
+        return None
+
+    @property
+    def terminal(self):
+        n = len(self.history)
+        if n < 5:
+            return False
+        return n == 9 or self.winner is not None
+
+    def render(self, turn=None):
+        if turn is not None:
+            assert 0 <= turn <= len(self.history)
+            hist = self.history[:turn]
+        else:
+            hist = self.history
+        img = np.zeros((2, 9), dtype=np.float32)
+        # plane 0: squares of the player to move in the FULL game, as the reference indexes them
+        img[0, hist[self.next_player::2]] = 1
+        img[1, hist[self.prev_player::2]] = 1
+        return img.reshape(2, 3, 3)
+
+    def __str__(self):
+        h = self.history
+        t = [' ' if i not in h else 'XO'[h.index(i) % 2] for i in range(9)]
+        bar = '\n' + '-' * 11 + '\n'
+        return bar.join(' ' + ' | '.join(t[r:r + 3]) for r in (0, 3, 6))

@@ -1,0 +1,110 @@
+"""SelfPlayWorker with the reference's constructor and `play_game()` contract
+(alphazero/selfplay.py:5-42), running `num_games` games concurrently on one GPU.
+
+The reference plays one game per call; here one call advances every game slot in
+lock-step, move by move, until at least one game has finished, hands each finished
+game to `dataset.add_game(game, model_version)` as a `Game` object carrying the
+history and per-move visit counts, and returns the model version -- so the loops in
+the reference's train.py (`while version < num_steps: worker.play_game()`) work as
+they are.  Collaborators are duck-typed exactly as in the reference:
+`model_server.latest(model) -> int`, `dataset.add_game(game, version)`,
+`config.Game()`, `config.Model()`, `config.selfplay[...]`.
+"""
+import numpy as np
+import torch
+
+from . import engine as _engine
+from .mcts import evaluate_leaves
+from .models import UniformModel
+
+
+def record_to_game(game_cls, rec):
+    """az_game_record -> Game with history and compacted uint32 visit counts per move."""
+    n = rec.num_moves
+    hist = [int(rec.history[i]) for i in range(n)]
+    stats = [np.array(rec.visits[i][:rec.num_edges[i]], dtype=np.uint32) for i in range(n)]
+    return game_cls(history=hist, search_statistics=stats)
+
+
+class SelfPlayWorker:
+    def __init__(self, config, model_server, dataset, device, num_games=1024, seed=0,
+                 rank=0, world_size=1, evaluator=None):
+        self._config = config
+        self._model_server = model_server
+        self._dataset = dataset
+        self._device = torch.device(device)
+        self._model = config.Model().to(self._device)
+        self._game_cls = type(config.Game())
+        sp = config.selfplay
+        self.num_games = int(num_games)
+        self.num_simulations = int(sp['num_expansions_per_sim'])
+        dev_index = self._device.index if self._device.index is not None else torch.cuda.current_device()
+        self.engine = _engine.SelfPlayEngine(
+            self._game_cls.AZ_GAME_ID, self.num_games, self.num_simulations,
+            exploration_depth=sp['exploration_depth'], reuse_search_tree=sp['reuse_search_tree'],
+            seed=seed, device=dev_index, first_game_uid=rank * self.num_games,
+            uid_stride=world_size * self.num_games)
+        self._evaluator = evaluator           # callable(leaf_bb, leaf_info) -> (p, v); None = torch model
+        self._version = 0
+        self.positions = 0
+        self.games_finished = 0
+
+    # ---- one move for every game slot -----------------------------------------------
+    def _eval(self, bb, info):
+        if self._evaluator is not None:
+            return self._evaluator(bb, info)
+        return evaluate_leaves(self.engine.game, self._model, bb, info)
+
+    def play_move(self, uniform):
+        eng, S = self.engine, self.num_simulations
+        if uniform:
+            # UniformModel (selfplay.py:19-22) is evaluated inside the search kernel
+            eng.begin_move_uniform()
+            eng.run_sims_uniform(S)
+        else:
+            bb, info = eng.begin_move()
+            p, _ = self._eval(bb, info)
+            eng.apply_root(p)
+            if S > 0:
+                bb, info = eng.select()
+                for _ in range(S - 1):
+                    p, v = self._eval(bb, info)
+                    bb, info = eng.sim_step(p, v)
+                p, v = self._eval(bb, info)
+                eng.expand_backup(p, v)
+        eng.choose_and_advance()
+        self.positions += self.num_games
+
+    def collect_finished(self):
+        recs = self.engine.drain_finished()
+        for r in recs:
+            self._dataset.add_game(record_to_game(self._game_cls, r), int(r.model_version))
+        self.games_finished += len(recs)
+        return len(recs)
+
+    def refresh_model(self):
+        """selfplay.py:16-22: pull the latest weights; version 0 means 'no model yet'."""
+        self._version = int(self._model_server.latest(self._model))
+        self.engine.set_model_version(self._version)
+        return self._version
+
+    def play_game(self):
+        version = self.refresh_model()
+        uniform = version <= 0 and self._evaluator is None
+        finished = 0
+        while finished == 0:
+            self.play_move(uniform)
+            finished = self.collect_finished()
+        return version
+
+    def play_moves(self, num_moves):
+        """Throughput-oriented loop: `num_moves` lock-step moves, finished games collected at the end."""
+        version = self.refresh_model()
+        uniform = version <= 0 and self._evaluator is None
+        for _ in range(num_moves):
+            self.play_move(uniform)
+            # the ring holds 2*G records; a slot finishes at most one game per move
+            if (_ + 1) % 2 == 0:
+                self.collect_finished()
+        self.collect_finished()
+        return version

@@ -1,0 +1,183 @@
+/*
+ * azhip.h -- C ABI of libazhip.so, the MI355X (gfx950) self-play engine.
+ *
+ * The reference (mtb2718/alphazero) is pure Python and has no FFI layer; its
+ * boundary is the duck-typed Python surface Game / MCTreeNode / run_mcts /
+ * SelfPlayWorker.  This library is what that surface binds to instead of the
+ * reference's per-object Python: each entry point names the reference code
+ * (file:line, relative to the reference checkout) whose work it does for G
+ * games at once.
+ *
+ * Conventions
+ *   - plain C types only; every pointer is either a HOST pointer or a DEVICE
+ *     pointer as marked;  no torch / C++ types cross the boundary.
+ *   - every call that launches work takes a hipStream_t (passed as void*) and
+ *     is stream-ordered and asynchronous unless marked "synchronous".
+ *   - return value: 0 = ok, negative = error; az_last_error() gives the text.
+ *   - one engine per device, driven by one host thread (like the reference,
+ *     not thread-safe).  The caller owns all I/O buffers, the engine owns the
+ *     node pools and per-game state.
+ *   - "slot" = index of an edge in a node's COMPACTED legal-move list, exactly
+ *     the reference's action_index (alphazero/mcts.py:124-126).
+ */
+#ifndef AZHIP_H
+#define AZHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AZ_GAME_TTT 0   /* alphazero/games/tictactoe.py:9-62   : 9 actions, 3x3 */
+#define AZ_GAME_C4  1   /* alphazero/games/connectfour.py:75-120: 7 actions, 6x7 */
+
+#define AZ_MAX_ACTIONS 9
+#define AZ_MAX_MOVES   42
+#define AZ_NO_NODE     0xFFFFFFFFu
+
+/* leaf_info word written by az_select / az_begin_move, one per game:
+ *   bits 0..7   kind      bits 8..15  number of moves played at the leaf
+ *   bits 16..24 legal-action mask of the leaf position                      */
+#define AZ_LEAF_NONE     0  /* nothing to evaluate for this game             */
+#define AZ_LEAF_EVAL     1  /* un-expanded non-terminal leaf: needs (p, v)   */
+#define AZ_LEAF_TERMINAL 2  /* terminal leaf: valued by the rules            */
+#define AZ_LEAF_ROOT     3  /* un-expanded search root: needs p (v unused)   */
+
+#define AZ_WINNER_NONE (-2)
+#define AZ_WINNER_DRAW (-1)
+
+typedef struct az_engine az_engine;
+
+typedef struct {
+    int32_t  game;               /* AZ_GAME_*                                             */
+    int32_t  num_games;          /* G concurrent games on this device                     */
+    int32_t  node_capacity;      /* nodes per game pool; 0 = S*max_moves+max_moves+1      */
+    int32_t  num_simulations;    /* S, config selfplay.num_expansions_per_sim             */
+    int32_t  exploration_depth;  /* config selfplay.exploration_depth (selfplay.py:26)    */
+    int32_t  reuse_search_tree;  /* config selfplay.reuse_search_tree (selfplay.py:34-38) */
+    int32_t  device;             /* HIP device ordinal                                    */
+    int32_t  model_version;      /* stamped into finished-game records                    */
+    double   alpha, epsilon;     /* Dirichlet noise, mcts.py:110 defaults 0.3 / 0.25      */
+    double   c_base, c_init;     /* mcts.py:52 defaults 19652 / 1.25                      */
+    uint64_t seed;               /* device RNG: stream of game uid = f(seed, uid)         */
+    uint64_t first_game_uid;     /* uid of game slot 0; slot g starts at first+g, and a
+                                    restarted slot continues at uid + uid_stride          */
+    uint64_t uid_stride;         /* 0 = num_games (set to world_size*G when sharded)      */
+} az_engine_config;
+
+/* one finished game, replaces the row written by
+ * SelfPlayDatabase.write_game (alphazero/replay_buffer.py:28-47)            */
+typedef struct {
+    uint64_t uid;
+    int32_t  num_moves;
+    int32_t  winner;                                   /* -1 draw, 0, 1      */
+    int32_t  model_version;
+    int32_t  reserved;
+    uint8_t  history[AZ_MAX_MOVES + 6];                /* actions            */
+    uint8_t  num_edges[AZ_MAX_MOVES + 6];              /* legal moves / move */
+    uint32_t visits[AZ_MAX_MOVES][AZ_MAX_ACTIONS];     /* compacted root N   */
+} az_game_record;
+
+/* throughput / roofline counters summed over games (host struct) */
+typedef struct {
+    uint64_t sims;          /* simulations completed                          */
+    uint64_t select_steps;  /* edges descended (sum of select depths)         */
+    uint64_t leaf_evals;    /* non-terminal leaves expanded                   */
+    uint64_t root_evals;    /* roots expanded                                 */
+    uint64_t moves;         /* positions produced                             */
+    uint64_t games;         /* games finished                                 */
+    uint64_t errors;        /* games that hit node-pool exhaustion            */
+} az_stats;
+
+const char* az_last_error(void);
+int  az_version(void);
+
+/* ---- engine lifetime (synchronous) ------------------------------------ */
+int  az_engine_create(const az_engine_config* cfg, az_engine** out);
+int  az_engine_destroy(az_engine* e);
+/* selfplay.py:13-14: every slot gets an empty game and an un-expanded root  */
+int  az_reset_games(az_engine* e, void* stream);
+/* PUCT table, HOST pointer, n rows of {Cs, sqrt(Ns)} indexed by Ns = sum N
+ * (mcts.py:55-57 evaluated by the host's numpy, so the transcendental is the
+ * reference's own).  Synchronous.                                            */
+int  az_set_puct_lut(az_engine* e, const double* lut_host, int32_t n);
+int  az_set_model_version(az_engine* e, int32_t version);
+
+/* ---- one move of self-play, lock-step over all G games ------------------
+ * selfplay.py:24-38 / mcts.py:110-158, per move:
+ *   az_begin_move   -> leaves for un-expanded roots           (mcts.py:114-115)
+ *   az_apply_root   <- p for those; noise on every root       (mcts.py:116-117)
+ *   S x { az_select -> leaves ; az_expand_backup <- p, v }    (mcts.py:119-158)
+ *   az_choose_and_advance                                     (selfplay.py:26-38)
+ * DEVICE buffers: leaf_bb uint64[G][2] = {stones of side to move, stones of
+ * previous mover} as bitboards (C4: bit col*7+row; TTT: bit square);
+ * leaf_info int32[G]; p float[G][A] = ACTION-indexed soft-maxed priors
+ * (entries of illegal actions ignored); v float[G].                          */
+int  az_begin_move(az_engine* e, uint64_t* leaf_bb, int32_t* leaf_info, void* stream);
+/* eta: DEVICE double[G][A] slot-indexed Dirichlet draws, or NULL = device RNG */
+int  az_apply_root(az_engine* e, const float* p, const double* eta, void* stream);
+int  az_select(az_engine* e, uint64_t* leaf_bb, int32_t* leaf_info, void* stream);
+int  az_expand_backup(az_engine* e, const float* p, const float* v, void* stream);
+/* fused az_expand_backup (if p != NULL) followed by az_select               */
+int  az_sim_step(az_engine* e, const float* p, const float* v,
+                 uint64_t* leaf_bb, int32_t* leaf_info, void* stream);
+/* num_sims simulations per game inside ONE launch with the UniformModel
+ * evaluated in place (models.py:90-95: p = 1/n_legal, v = 0)                */
+int  az_run_sims_uniform(az_engine* e, int32_t num_sims, void* stream);
+/* roots needing expansion get the uniform prior in place, then noise (eta as
+ * in az_apply_root)                                                          */
+int  az_begin_move_uniform(az_engine* e, const double* eta, void* stream);
+/* u: DEVICE double[G] uniforms for sample_action, or NULL = device RNG.
+ * Optional DEVICE outputs (may be NULL): action int32[G], num_edges int32[G],
+ * visits uint32[G][A] (compacted, zero padded), winner int32[G]
+ * (AZ_WINNER_NONE while the game goes on).  Finished games are appended to
+ * the engine's record ring and their slot restarts with a new uid.          */
+int  az_choose_and_advance(az_engine* e, const double* u, int32_t* action, int32_t* num_edges,
+                           uint32_t* visits, int32_t* winner, void* stream);
+
+/* ---- finished games (synchronous on `stream`) --------------------------
+ * copies up to max_records finished games to HOST memory and empties the ring;
+ * replaces ReplayBufferDataset.add_game (replay_buffer.py:165-167)          */
+int  az_drain_finished(az_engine* e, az_game_record* out_host, int32_t max_records,
+                       int32_t* num_out, void* stream);
+int  az_get_stats(az_engine* e, az_stats* out_host, void* stream);
+
+/* ---- tree transfer for the single-game MCTreeNode / run_mcts mirror ------
+ * node image (HOST): uint32[num_nodes][A+1][4]; edge i = {N, W bits, P bits,
+ * child index or AZ_NO_NODE}; last row = {num_edges, sum N, 0, 0}.
+ * az_set_position loads a root position (history replayed on the host side
+ * into bitboards by the caller) and a tree for game slot g; root_node may be
+ * AZ_NO_NODE for an un-expanded root.  Synchronous.                          */
+int  az_set_position(az_engine* e, int32_t g, uint64_t bb_next, uint64_t bb_prev, int32_t num_moves,
+                     const uint32_t* nodes_host, int32_t num_nodes, uint32_t root_node);
+int  az_get_tree(az_engine* e, int32_t g, uint32_t* nodes_host, int32_t max_nodes,
+                 int32_t* num_nodes, uint32_t* root_node);
+int  az_node_words(const az_engine* e);   /* uint32 words per node = 4*(A+1) */
+
+/* ---- stateless bulk game kernels (K1-K4), DEVICE buffers -----------------
+ * hist uint8[n][stride], len int32[n]  ->  bitboards + rule queries
+ * (connectfour.py:80-120, tictactoe.py:26-62, game.py:23-47)               */
+int  az_positions_from_history(int32_t game, const uint8_t* hist, const int32_t* len, int32_t stride,
+                               int32_t n, uint64_t* bb, int32_t* num_moves, void* stream);
+int  az_game_query(int32_t game, const uint64_t* bb, const int32_t* num_moves, int32_t n,
+                   int32_t* legal_mask, int32_t* terminal, int32_t* winner, void* stream);
+int  az_game_step(int32_t game, uint64_t* bb, int32_t* num_moves, const int32_t* action, int32_t n,
+                  int32_t* status, void* stream);
+/* x float[n][2][H][W], plane 0 = side to move (connectfour.py:112-120);
+ * valid uint8[n][A] (mcts.py:103-104); either may be NULL                    */
+int  az_render(int32_t game, const uint64_t* bb, int32_t n, float* x, uint8_t* valid, void* stream);
+/* mcts.py:106: softmax over the legal logits only; p float[n][A], zeros at
+ * illegal actions.  legal from leaf_info (bits 16..24).                      */
+int  az_masked_softmax(int32_t game, const float* logits, const int32_t* leaf_info, int32_t n,
+                       float* p, void* stream);
+/* mcts.py:52-59 for n nodes given as arrays (N uint32, W, P float, [n][A],
+ * num_edges int32[n]) -> score double[n][A], argmax int32[n]; uses the
+ * engine's PUCT table                                                        */
+int  az_ucb_score(az_engine* e, const uint32_t* N, const float* W, const float* P,
+                  const int32_t* num_edges, int32_t n, double* score, int32_t* argmax, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,47 @@
+"""Node-level numerics on the GPU: PUCT score / arg-max (az_ucb_score), masked soft-max."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_json, load_lut, unhex
+
+pytestmark = pytest.mark.gpu
+
+
+def test_ucb_score_bits_match_reference():
+    from alphazero_amd import engine as E
+    from alphazero_amd._lib import check, ptr
+    cases = load_json('nodes.json')
+    eng = E.SelfPlayEngine(0, 1, 1, lut=load_lut())          # TTT: 9 edge slots
+    n, A = len(cases), 9
+    N = np.zeros((n, A), np.uint32); W = np.zeros((n, A), np.float32); P = np.zeros((n, A), np.float32)
+    ne = np.zeros(n, np.int32)
+    for i, c in enumerate(cases):
+        k = c['n']; ne[i] = k
+        N[i, :k] = c['N']; W[i, :k] = unhex(c['W'], '<f4'); P[i, :k] = unhex(c['P'], '<f4')
+    dN, dW, dP, dne = (torch.from_numpy(a).cuda() for a in (N.view(np.int32), W, P, ne))
+    score = torch.zeros(n, A, dtype=torch.float64, device='cuda')
+    am = torch.zeros(n, dtype=torch.int32, device='cuda')
+    check(eng.lib.az_ucb_score(eng.h, ptr(dN), ptr(dW), ptr(dP), ptr(dne), n, ptr(score), ptr(am), None))
+    torch.cuda.synchronize()
+    score, am = score.cpu().numpy(), am.cpu().numpy()
+    for i, c in enumerate(cases):
+        assert score[i, :c['n']].tobytes() == unhex(c['ucb'], '<f8').tobytes(), i
+        assert am[i] == c['argmax'], i
+
+
+def test_masked_softmax_matches_torch():
+    from alphazero_amd import engine as E
+    rng = np.random.RandomState(0)
+    for game, A in ((1, 7), (0, 9)):
+        n = 513
+        logits = torch.from_numpy(rng.randn(n, A).astype(np.float32) * 3).cuda()
+        legal = rng.randint(1, 1 << A, size=n).astype(np.int32)
+        info = torch.from_numpy((legal << 16) | 1).cuda()
+        p = E.masked_softmax(game, logits, info).cpu()
+        for i in range(n):
+            m = torch.tensor([(legal[i] >> a) & 1 for a in range(A)], dtype=torch.bool)
+            ref = torch.softmax(logits[i].cpu()[m], 0)
+            # tolerance: 1e-5 relative, the bound stated for net outputs in fp32
+            assert torch.allclose(p[i][m], ref, rtol=1e-5, atol=1e-7)
+            assert torch.all(p[i][~m] == 0)
