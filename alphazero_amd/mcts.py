@@ -243,7 +243,7 @@ def run_mcts(game, root, model, num_simulations, alpha=0.3, epsilon=0.25):
     img, objs = _flatten(root, A)
     eng = _single_engine(game_id, float(alpha), float(epsilon), img.shape[0] + num_simulations + 2)
     nx, pv, nm = game.position()
-    eng.set_position(0, nx, pv, nm, img.reshape(img.shape[0], -1), 0 if len(objs) else NO_NODE)
+    eng.set_position(0, nx, pv, nm, img if len(objs) else None, 0 if len(objs) else NO_NODE)
     dev = eng.device
 
     # mcts.py:114-117: expand the root if needed, then noise from numpy's global RNG
@@ -263,7 +263,6 @@ def run_mcts(game, root, model, num_simulations, alpha=0.3, epsilon=0.25):
     eng.apply_root(p, eta)
 
     v = torch.zeros(1, dtype=torch.float32, device=dev)
-    valid_buf = torch.zeros(A, dtype=torch.bool)
     for _ in range(num_simulations):
         leaf_bb, leaf_info = eng.select()
         info = int(leaf_info[0].item())
@@ -281,6 +280,5 @@ def run_mcts(game, root, model, num_simulations, alpha=0.3, epsilon=0.25):
             p[0, valid[0]] = pc.to(dev, torch.float32)
             v[0] = val.reshape(-1)[0].to(dev, torch.float32)
         eng.expand_backup(p, v)
-    del valid_buf
     st_img, root_idx = eng.get_tree(0)
     _unflatten(st_img, objs, root, root_idx, A)
