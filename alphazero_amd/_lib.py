@@ -67,6 +67,8 @@ SIGNATURES = {
     'az_render': (C.c_int, [C.c_int32, _P, C.c_int32, _P, _P, _P]),
     'az_masked_softmax': (C.c_int, [C.c_int32, _P, _P, C.c_int32, _P, _P]),
     'az_ucb_score': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, _P, _P, _P]),
+    'az_c4net_blob_bytes': (C.c_int, []),
+    'az_c4net_bf16_forward': (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P, _P, _P]),
 }
 
 _lib = None

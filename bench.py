@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""Self-play throughput benchmark (BASELINE.json metric: Connect4 self-play positions/s
+and MCTS sims/s at 800 sims/move, 8192 concurrent games per GPU).
+
+One "step" = one lock-step move of the hot path: every one of the G game slots on this
+rank runs S PUCT simulations (select -> leaf eval -> expand/backup) and plays a move,
+so a step produces G positions and G*S simulations per rank.  Inputs are synthetic:
+all games start from the empty board, finished games restart at once, network weights
+are random-initialised (throughput does not depend on their values).
+
+  python bench.py --gpus N --steps K --warmup W [--model uniform|c4_6x32|c4_10x128]
+                  [--games G] [--sims S] [--no-cpu-baseline]
+
+Launched by torch.distributed.run for N > 1 (one rank per GPU, RCCL); games shard across
+ranks with no data-path collective (scaling: weak), weights are broadcast from rank 0 once
+per step when a network is in use.  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
+BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak
+F32_PEAK_TFLOPS = 157.3        # f32 MFMA / vector peak
+
+
+def bytes_per_sim(d, f):
+    """Algorithmic HBM bytes per simulation: root state 24 B + per select level one 112-B
+    node read and a 16-B backup read-modify-write + per expanded leaf a 120-B node write,
+    32 B of (p, v) and a 24-B leaf state."""
+    return 24.0 + 128.0 * d + 176.0 * f
+
+
+def trunk_flops_per_leaf(blocks, ch, cells=42, planes=2):
+    conv = 2 * 9 * ch * ch * cells
+    return 2 * blocks * conv + 2 * 9 * planes * ch * cells
+
+
+def cpu_baseline(model_name, sims, seconds, workers):
+    """The CPU oracle (oracle/az_oracle.c, the restatement of the reference's algorithm)
+    playing whole games, one independent single-game worker per core as `train.py -n N`
+    does (alphazero/train.py:131-134).  Bounded sample: each worker plays for ~`seconds`."""
+    import multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    with ctx.Pool(workers) as pool:
+        res = pool.starmap(_cpu_worker, [(model_name, sims, seconds, w) for w in range(workers)])
+    pos = sum(r[0] for r in res)
+    sim = sum(r[1] for r in res)
+    wall = max(r[2] for r in res)
+    return pos / wall, sim / wall, pos, wall
+
+
+def _cpu_worker(model_name, sims, seconds, wid):
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import numpy as np
+    import oracle as orc
+    from alphazero_amd.engine import make_puct_lut
+    lut = orc.make_lut_array(make_puct_lut(sims * 42 + 64))
+    cfg = orc.make_config(orc.C4, sims, 4, True, lut)
+    if model_name == 'uniform':
+        ev = orc.eval_uniform()
+    else:
+        import torch
+        torch.set_num_threads(1)
+        from alphazero_amd.models import AlphaZeroC4
+        blocks, ch = (6, 32) if model_name == 'c4_6x32' else (10, 128)
+        torch.manual_seed(0)
+        net = AlphaZeroC4(blocks, ch).eval()
+
+        def fn(game, hist, valid):          # one net call per leaf, batch 1 (mcts.py:94-107)
+            x = torch.from_numpy(orc.render(game, hist)[None])
+            m = torch.zeros(1, 7, dtype=torch.bool)
+            m[0, valid] = True
+            with torch.no_grad():
+                lg, v = net(x, m)
+                p = torch.softmax(lg[m], 0)
+            return p.numpy(), float(v[0, 0])
+        ev = orc.eval_from_python(fn)
+    t0 = time.time()
+    pos = sim = 0
+    seed = 1000 + wid
+    while time.time() - t0 < seconds:
+        st = orc.Stats()
+        rec = orc.play_game_builtin_rng(cfg, ev, seed, st)
+        seed += 100
+        pos += rec.num_moves
+        sim += st.sims
+    return pos, sim, time.time() - t0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=4)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--model', default='uniform', choices=['uniform', 'c4_6x32', 'c4_10x128'])
+    ap.add_argument('--net-impl', default='hip', choices=['torch', 'hip'])
+    ap.add_argument('--games', type=int, default=8192)
+    ap.add_argument('--sims', type=int, default=800)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from alphazero_amd import engine as E
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device('cuda', local if world > 1 else 0)
+    G, S = args.games, args.sims
+
+    eng = E.SelfPlayEngine(E._lib.GAME_C4, G, S, exploration_depth=4, reuse_search_tree=True,
+                           alpha=0.3, epsilon=0.25, seed=0, device=dev.index,
+                           first_game_uid=rank * G, uid_stride=world * G)
+
+    net = None
+    if args.model != 'uniform':
+        from alphazero_amd.models import AlphaZeroC4
+        from alphazero_amd.mcts import evaluate_leaves
+        blocks, ch = (6, 32) if args.model == 'c4_6x32' else (10, 128)
+        torch.manual_seed(0)
+        net = AlphaZeroC4(blocks, ch).to(dev).eval()
+        flat = torch.nn.utils.parameters_to_vector(net.parameters()).detach()
+        if args.net_impl == 'hip':
+            from alphazero_amd.net import FusedC4Net
+            fused = FusedC4Net.from_module(net, dev)
+            evaluate = lambda bb, info: fused(bb, info)
+        else:
+            evaluate = lambda bb, info: evaluate_leaves(eng.game, net, bb, info)
+
+    ev_start = torch.cuda.Event(enable_timing=True)
+    ev_end = torch.cuda.Event(enable_timing=True)
+    kern_ms = []       # per-launch duration of the dominant kernel, HIP events
+
+    def one_step(timed):
+        if net is None:
+            eng.begin_move_uniform()
+            if timed:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+            eng.run_sims_uniform(S)
+            if timed:
+                b.record()
+                kern_ms.append((a, b))
+        else:
+            if world > 1:                      # RCCL weight broadcast replaces model_server.latest()
+                dist.broadcast(flat, 0)
+            bb, info = eng.begin_move()
+            p, _ = evaluate(bb, info)
+            eng.apply_root(p)
+            bb, info = eng.select()
+            for s in range(S):
+                p, v = evaluate(bb, info)
+                if s < S - 1:
+                    bb, info = eng.sim_step(p, v)
+                else:
+                    eng.expand_backup(p, v)
+        eng.choose_and_advance()
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step(False)
+    eng.drain_finished()
+    st0 = eng.stats()
+    sync_all()
+    t0 = time.perf_counter()
+    ev_start.record()
+    for i in range(args.steps):
+        one_step(True)
+    ev_end.record()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    st1 = eng.stats()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    sims = st1['sims'] - st0['sims']
+    steps_sel = st1['select_steps'] - st0['select_steps']
+    evals = st1['leaf_evals'] - st0['leaf_evals']
+    d = steps_sel / max(sims, 1)
+    f = evals / max(sims, 1)
+    assert sims == G * S * args.steps, (sims, G * S * args.steps)
+    assert st1['errors'] == 0, 'node pool exhausted'
+
+    positions = world * G * args.steps
+    out = {
+        'metric': 'Connect4 self-play positions/s (800 sims/move)',
+        'value': positions / elapsed,
+        'unit': 'positions/s',
+        'sims_per_s': world * sims / elapsed,
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * elapsed / args.steps,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f64 PUCT / f32 W,P / u32 N' + ('' if net is None else ' ; f32 net'),
+        'data': 'synthetic',
+        'config': {'workload': f'connect4 self-play, {S} sims/move, {G} games/GPU, '
+                               f'exploration_depth 4, reuse_search_tree, model {args.model}',
+                   'games_per_gpu': G, 'sims_per_move': S, 'model': args.model,
+                   'net_impl': None if net is None else args.net_impl,
+                   'mean_select_depth': d, 'leaf_eval_fraction': f},
+    }
+    if rank == 0:
+        if kern_ms:
+            ms = sum(a.elapsed_time(b) for a, b in kern_ms) / len(kern_ms)
+            alg = bytes_per_sim(d, f) * G * S           # bytes one launch moves, algorithmically
+            gbs = alg / (ms * 1e-3) / 1e9
+            out['roofline'] = {'kernel': 'k_run_uniform<GameC4>', 'bound': 'hbm', 'achieved': gbs,
+                               'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+                               'traffic': None, 'avg_launch_ms': ms,
+                               'bytes_per_sim': bytes_per_sim(d, f)}
+        if not args.no_cpu_baseline:
+            workers = min(16, os.cpu_count() or 1)
+            pps, sps, npos, wall = cpu_baseline(args.model, S, args.cpu_seconds, workers)
+            out['cpu_baseline'] = {'value': pps, 'unit': 'positions/s', 'sims_per_s': sps, 'cores': workers,
+                                   'kind': 'port',
+                                   'sample': f'{npos} positions of whole oracle games in {wall:.1f} s, '
+                                             f'{workers} independent single-game workers, model {args.model}'}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -177,6 +177,16 @@ int  az_masked_softmax(int32_t game, const float* logits, const int32_t* leaf_in
 int  az_ucb_score(az_engine* e, const uint32_t* N, const float* W, const float* P,
                   const int32_t* num_edges, int32_t n, double* score, int32_t* argmax, void* stream);
 
+/* ---- fused Connect Four network forward (K8/K12) ---------------------------
+ * Whole AlphaZeroC4 forward (alphazero/models.py:70-87, connectfour.py:54-72) for n
+ * leaves given as bitboards, BN folded, trunk channels <= 32, bf16 MFMA trunk with
+ * fp32 accumulation; writes p float[n][7] (soft-max over legal columns, zeros at full
+ * columns, mcts.py:106) and v float[n].  blob = DEVICE buffer of az_c4net_blob_bytes()
+ * bytes packed by alphazero_amd/net.py (layout in csrc/az_net.hip).               */
+int  az_c4net_blob_bytes(void);
+int  az_c4net_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uint64_t* leaf_bb,
+                           const int32_t* leaf_info, int32_t n, float* p, float* v, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,62 @@
+"""Fused HIP network forward against the fp32 torch statement of the same network."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_positions(n, seed):
+    rng = np.random.RandomState(seed)
+    hists = []
+    while len(hists) < n:
+        h = []
+        depth = rng.randint(0, 31)
+        while len(h) < depth and not orc.terminal(orc.C4, h):
+            h.append(int(rng.choice(orc.valid_actions(orc.C4, h))))
+        if not orc.terminal(orc.C4, h):
+            hists.append(h)
+    return hists
+
+
+def _randomize_bn(m, seed):
+    g = torch.Generator().manual_seed(seed)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.uniform_(-0.2, 0.2, generator=g)
+            mod.running_var.uniform_(0.5, 1.5, generator=g)
+            mod.weight.data.uniform_(0.5, 1.5, generator=g)
+            mod.bias.data.uniform_(-0.2, 0.2, generator=g)
+
+
+@pytest.mark.parametrize('blocks,ch,n', [(6, 32, 1000), (2, 8, 37), (1, 32, 16), (3, 16, 512)])
+def test_fused_bf16_forward_matches_torch_fp32(blocks, ch, n):
+    from alphazero_amd import engine as E
+    from alphazero_amd.models import AlphaZeroC4
+    from alphazero_amd.net import FusedC4Net
+    torch.manual_seed(blocks * 100 + ch)
+    model = AlphaZeroC4(blocks, ch).eval()
+    _randomize_bn(model, 5)
+    hists = _random_positions(n, 11)
+    bb, nm = E.positions_from_history(1, hists)
+    legal, _, _ = E.game_query(1, bb, nm)
+    info = ((legal << 16) | 1).to(torch.int32)
+    net = FusedC4Net.from_module(model, 'cuda')
+    p, v = net(bb, info)
+    p, v = p.cpu(), v.cpu()
+    x, valid = E.render(1, bb)
+    with torch.no_grad():
+        logits, vref = model(x.cpu(), valid.cpu())
+    valid = valid.cpu()
+    pref = torch.zeros_like(logits)
+    for i in range(n):
+        pref[i, valid[i]] = torch.softmax(logits[i, valid[i]], 0)
+    assert torch.all(p[~valid] == 0)
+    assert torch.allclose(p.sum(1), torch.ones(n), atol=1e-5)
+    # bf16 trunk (8-bit mantissa activations and weights, fp32 accumulation): tolerance 5e-3 absolute
+    # on probabilities and values, which are O(1) quantities
+    assert (p - pref).abs().max().item() < 5e-3, (p - pref).abs().max().item()
+    assert (v - vref.reshape(-1)).abs().max().item() < 5e-3, (v - vref.reshape(-1)).abs().max().item()
+    print('max |dp|', (p - pref).abs().max().item(), 'max |dv|', (v - vref.reshape(-1)).abs().max().item())
