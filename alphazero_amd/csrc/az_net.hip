@@ -3,105 +3,198 @@
 // The whole network of alphazero/models.py:70-87 + alphazero/games/connectfour.py:54-72
 // (stem conv, tower of one residual block applied num_blocks times, policy and value
 // heads, landing-cell gather, soft-max over legal columns) runs in ONE kernel for up to
-// 32 trunk channels.  A workgroup takes 16 leaf positions straight from their bitboards,
-// keeps every activation in LDS from the first conv to the last, and writes only
-// p[7] and v per leaf: HBM traffic is 16 B in and 32 B out per leaf, so the kernel is
-// bounded by the MFMA rate, not by memory.
+// 32 trunk channels.  A persistent workgroup takes 16 leaf positions at a time straight
+// from their bitboards, keeps every activation in LDS from the first conv to the last and
+// writes only p[7] and v per leaf: HBM traffic is 16 B in and 32 B out per leaf, so the
+// kernel is bounded by the matrix-core rate, not by memory.
 //
-// Convolutions are implicit GEMMs on the matrix cores: D[co][pos] = sum_k Wt[co][k] X[k][pos]
-// with k = (tap, ci).  v_mfma_f32_32x32x16_bf16: A = folded weights, held in registers for
-// the whole kernel (a lane's fragment of both tower convs is 144 VGPRs); B = activations
-// read from LDS with one ds_read_b128 per MFMA.  Batch-norm (eval mode) is folded into the
-// weights and a per-channel bias on the host.
+// Every contraction is an MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulate), oriented
+// D[out][pos] = sum_k Wt[out][k] X[k][pos]:
+//   * A = weights.  The two tower convs' fragments stay in registers for the whole kernel
+//     (144 VGPRs per lane); stem / head fragments are small and fetched when used.
+//   * B = activations, one ds_read_b128 per MFMA.  The stem's B operand is built in
+//     registers from the two bitboards (K = 9 taps x 2 planes = 18, padded to 32).
+//   * D puts the position on the lane and 4 consecutive channels in 4 registers, so the
+//     epilogue (residual add, ReLU, bf16) writes 8 bytes per ds_write_b64.
+// Batch-norm (eval mode) is folded into weights and a per-channel bias on the host; the
+// bias is the accumulator's initial value.
 //
-// LDS activation image, per board: 66 positions x 32 channels bf16 (64 B per position).
-// Positions form an 8-wide grid with one zero column and zero rows above and below, so a
-// 3x3 tap is a constant position offset and needs no bounds test; 48 of them (6 rows x 8)
-// are computed per conv, the 8th column is masked back to zero.  The four 16-byte channel
-// chunks of a position are XOR-swizzled with (pos >> 2) & 3 so the 16 lanes of a
-// ds_read_b128 group always hit 16 different 16-byte bank slots.
+// LDS activation image: positions on an 8-wide grid, 80 bytes apart (32 bf16 channels +
+// 16 B pad: 5 slots of 16 B, coprime with the 16 slots of a bank row, so the 16 lanes of a
+// ds_read_b128 group always land on 16 different slots).  Board b owns 56 positions: one
+// zero row, then 6 rows of 7 cells + 1 zero cell; the zero row of board b+1 closes board b.
+// A 3x3 tap is therefore a constant byte offset folded into the ds_read instruction; the
+// 8th column is computed like a cell and masked back to zero when stored.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <string>
 
 #include "../../include/azhip.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-#define TB 16                    // boards per workgroup
-#define NPOS 66                  // padded positions per board
-#define POS0 9                   // first computed position (1 guard + one zero row of 8)
+#define TB 16                     // boards per workgroup iteration
+#define PSTRIDE 80                // bytes per position
+#define BOARD_POS 56              // positions per board (zero row + 6 rows of 8)
+#define POS0 9                    // guard + zero row
+#define NPOS_TOTAL (1 + TB * BOARD_POS + 8 + 1)
+#define ACT_BYTES (((NPOS_TOTAL * PSTRIDE) + 255) / 256 * 256)
 #define NTHREADS 512
-#define NWAVES 8
-#define TILES_PER_WAVE 3         // TB*48/32 = 24 tiles of 32 positions
-#define ACT_BYTES (TB * NPOS * 64)
+#define TILES_PER_WAVE 3          // TB*48/32 = 24 tiles of 32 positions over 8 waves
+
+// LDS scratch after the two activation images
+#define S_BIAS 0                              // float[3][32] + head bias [4]  (400 B -> 512)
+#define S_HP 512                              // bf16 [TB][96] policy planes, k = ch*42 + cell
+#define S_HV (S_HP + TB * 96 * 2)             // bf16 [TB][48] value plane
+#define S_LG (S_HV + TB * 48 * 2)             // float [TB][64] cell logits
+#define S_VP (S_LG + TB * 64 * 4)             // float [8][32] value partial sums per wave
+#define S_BYTES (S_VP + 8 * 32 * 4)
+#define LDS_BYTES (2 * ACT_BYTES + S_BYTES)
 
 // blob layout (bytes); must match alphazero_amd/net.py
-#define OFF_WF 0                                  // [3][18][64][8] bf16
-#define OFF_HF (OFF_WF + 3 * 18 * 64 * 16)        // [2][64][8] bf16
-#define OFF_BIAS (OFF_HF + 2 * 64 * 16)           // [3][32] f32
-#define OFF_HB (OFF_BIAS + 3 * 32 * 4)            // [4] f32
-#define OFF_WP (OFF_HB + 16)                      // [42][84] f32
-#define OFF_BP (OFF_WP + 42 * 84 * 4)             // [44] f32 (42 used)
-#define OFF_W1T (OFF_BP + 44 * 4)                 // [42][256] f32
-#define OFF_B1 (OFF_W1T + 42 * 256 * 4)           // [256] f32
-#define OFF_W2 (OFF_B1 + 256 * 4)                 // [256] f32
-#define OFF_B2 (OFF_W2 + 256 * 4)                 // [4] f32
+#define OFF_SF 0                                   // stem      [2][64][8] bf16
+#define OFF_WF (OFF_SF + 2 * 1024)                 // c1, c2    [2][18][64][8] bf16
+#define OFF_HF (OFF_WF + 2 * 18 * 1024)            // 1x1 heads [2][64][8] bf16
+#define OFF_F1 (OFF_HF + 2 * 1024)                 // value FC1 [8][3][64][8] bf16
+#define OFF_PF (OFF_F1 + 8 * 3 * 1024)             // policy FC [2][6][64][8] bf16
+#define OFF_BIAS (OFF_PF + 2 * 6 * 1024)           // float [3][32] stem, c1, c2 ; then [4] heads
+#define OFF_BP (OFF_BIAS + 100 * 4)                // float [64] policy FC bias
+#define OFF_B1 (OFF_BP + 64 * 4)                   // float [256]
+#define OFF_W2 (OFF_B1 + 256 * 4)                  // float [256]
+#define OFF_B2 (OFF_W2 + 256 * 4)                  // float [4]
 #define BLOB_BYTES (OFF_B2 + 16)
 
-__device__ __forceinline__ int act_addr(int pos, int chunk) {
-    return pos * 64 + ((chunk ^ ((pos >> 2) & 3)) << 4);
-}
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
 struct Weights { bf16x8 f[18]; };
 
-__device__ __forceinline__ void load_weights(Weights& w, const uint8_t* blob, int conv, int lane) {
-    const bf16x8* src = reinterpret_cast<const bf16x8*>(blob + OFF_WF) + (size_t)conv * 18 * 64 + lane;
-#pragma unroll
-    for (int s = 0; s < 18; ++s) w.f[s] = src[s * 64];
+__device__ __forceinline__ const bf16x8* frag_ptr(const uint8_t* blob, int off, int lane) {
+    return reinterpret_cast<const bf16x8*>(blob + off) + lane;
 }
 
-// one 3x3 conv over the workgroup's 16 boards: src -> dst (+ residual from dst itself when RES)
+// accumulator = per-channel bias: register r holds channel (r&3) + 8*(r>>2) + 4*h
+__device__ __forceinline__ f32x16 bias_acc(const float* bias, int h) {
+    f32x16 acc;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bias + 8 * g + 4 * h);
+        acc[4 * g] = b[0]; acc[4 * g + 1] = b[1]; acc[4 * g + 2] = b[2]; acc[4 * g + 3] = b[3];
+    }
+    return acc;
+}
+
+// (+ residual from dst) -> ReLU -> bf16 -> dst, 4 channels per 8-byte store
+template <bool RES>
+__device__ __forceinline__ void store_tile(const f32x16& acc, uint8_t* dst, int pos, int h) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        uint8_t* q = dst + pos * PSTRIDE + g * 16 + h * 8;
+        float x0 = acc[4 * g], x1 = acc[4 * g + 1], x2 = acc[4 * g + 2], x3 = acc[4 * g + 3];
+        if (RES) {
+            const uint2 r = *reinterpret_cast<const uint2*>(q);
+            x0 += __uint_as_float(r.x << 16); x1 += __uint_as_float(r.x & 0xFFFF0000u);
+            x2 += __uint_as_float(r.y << 16); x3 += __uint_as_float(r.y & 0xFFFF0000u);
+        }
+        bf16x4 y;
+        y[0] = (__bf16)fmaxf(x0, 0.0f); y[1] = (__bf16)fmaxf(x1, 0.0f);
+        y[2] = (__bf16)fmaxf(x2, 0.0f); y[3] = (__bf16)fmaxf(x3, 0.0f);
+        *reinterpret_cast<bf16x4*>(q) = y;
+    }
+}
+
+// fragments of one row of taps (3 taps x 2 channel halves) for a tile
+__device__ __forceinline__ void load_taps(bf16x8 (&f)[6], const uint8_t* base, int row) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int d = ((row - 1) * 8 + (i - 1)) * PSTRIDE;
+        f[2 * i] = *reinterpret_cast<const bf16x8*>(base + d);
+        f[2 * i + 1] = *reinterpret_cast<const bf16x8*>(base + d + 32);
+    }
+}
+
+// One 3x3 conv over the wave's own two boards (3 tiles of 32 positions): src -> dst (+ residual
+// read from dst when RES).  A wave's tiles only ever read positions of its own boards and the
+// never-written zero rows, so the tower needs no workgroup barrier: LDS operations of one wave
+// complete in issue order.  Loads run one row of taps ahead of the MFMAs that consume them.
 template <bool RES>
 __device__ __forceinline__ void conv3x3(const Weights& w, const uint8_t* src, uint8_t* dst, const float* bias,
                                         int wave, int lane) {
     const int h = lane >> 5;
+    int pos[TILES_PER_WAVE];
+    bool keep[TILES_PER_WAVE];
+    const uint8_t* base[TILES_PER_WAVE];
+#pragma unroll
+    for (int t = 0; t < TILES_PER_WAVE; ++t) {
+        const int R = (wave * TILES_PER_WAVE + t) * 32 + (lane & 31);
+        const int b = R / 48, o = R - b * 48;
+        pos[t] = b * BOARD_POS + POS0 + o;
+        keep[t] = (o & 7) != 7;
+        base[t] = src + pos[t] * PSTRIDE + h * 16;
+    }
+    bf16x8 fa[6], fb[6];
+    load_taps(fa, base[0], 0);
+#pragma unroll
+    for (int t = 0; t < TILES_PER_WAVE; ++t) {
+        f32x16 acc = bias_acc(bias, h);
+        load_taps(fb, base[t], 1);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc = MFMA(w.f[i], fa[i], acc);
+        load_taps(fa, base[t], 2);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc = MFMA(w.f[6 + i], fb[i], acc);
+        if (t + 1 < TILES_PER_WAVE) load_taps(fb, base[t + 1], 0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc = MFMA(w.f[12 + i], fa[i], acc);
+        if (keep[t]) store_tile<RES>(acc, dst, pos[t], h);
+        if (t + 1 < TILES_PER_WAVE) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) fa[i] = fb[i];
+        }
+    }
+}
+
+// stem conv 2 -> C straight from bitboards: B[k][pos], k = tap*2 + plane (18 of 32 used)
+__device__ __forceinline__ void stem(const uint8_t* blob, const uint64_t* leaf_bb, int board0, int n, uint8_t* dst,
+                                     const float* bias, int wave, int lane) {
+    const int h = lane >> 5;
+    const bf16x8 a0 = frag_ptr(blob, OFF_SF, lane)[0], a1 = frag_ptr(blob, OFF_SF, lane)[64];
 #pragma unroll 1
     for (int t = 0; t < TILES_PER_WAVE; ++t) {
         const int R = (wave * TILES_PER_WAVE + t) * 32 + (lane & 31);
         const int b = R / 48, o = R - b * 48;
-        const int pos = b * NPOS + POS0 + o;
-        f32x16 acc;
+        const int pos = b * BOARD_POS + POS0 + o;
+        const int y = o >> 3, x = o & 7;
+        const int gidx = board0 + b;
+        uint64_t bb[2] = {0, 0};
+        if (gidx < n) { bb[0] = leaf_bb[2 * (size_t)gidx] << 8; bb[1] = leaf_bb[2 * (size_t)gidx + 1] << 8; }
+        // after the shift, cell (xx, yy) with xx in -1..7, yy in -1..6 is bit (xx+1)*7 + yy + 1;
+        // out-of-board neighbours fall on guard bits, which are zero
+        bf16x8 f[2];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+        for (int s = 0; s < 2; ++s) {
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int p2 = pos + (tap / 3 - 1) * 8 + (tap % 3 - 1);
-            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(src + act_addr(p2, h));
-            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(src + act_addr(p2, 2 + h));
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.f[2 * tap], b0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.f[2 * tap + 1], b1, acc, 0, 0, 0);
-        }
-        // D: column = position (lane & 31), register r = channel (r&3) + 8*(r>>2) + 4*h
-        if ((o & 7) != 7) {
+            for (int j = 0; j < 8; ++j) {
+                // k = 16*s + 8*h + j; both values of h are formed and one selected, so that tap
+                // offsets stay compile-time constants
+                float v = 0.0f;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 bi = *reinterpret_cast<const float4*>(bias + 8 * g + 4 * h);
-                float x0 = acc[4 * g] + bi.x, x1 = acc[4 * g + 1] + bi.y, x2 = acc[4 * g + 2] + bi.z,
-                      x3 = acc[4 * g + 3] + bi.w;
-                uint8_t* q = dst + act_addr(pos, g) + 8 * h;
-                if (RES) {
-                    const bf16x4 r = *reinterpret_cast<const bf16x4*>(q);
-                    x0 += (float)r[0]; x1 += (float)r[1]; x2 += (float)r[2]; x3 += (float)r[3];
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int k = 16 * s + 8 * hh + j, tap = k >> 1, plane = k & 1;
+                    if (tap < 9) {
+                        const int sh = (x + tap % 3) * 7 + (y + tap / 3);     // (x+tx-1+1)*7 + (y+ty-1) + 1
+                        const float bit = (float)((bb[plane] >> sh) & 1ull);
+                        v = (hh == h) ? bit : v;
+                    }
                 }
-                bf16x4 y;
-                y[0] = (__bf16)fmaxf(x0, 0.0f); y[1] = (__bf16)fmaxf(x1, 0.0f);
-                y[2] = (__bf16)fmaxf(x2, 0.0f); y[3] = (__bf16)fmaxf(x3, 0.0f);
-                *reinterpret_cast<bf16x4*>(q) = y;
+                f[s][j] = (__bf16)v;
             }
         }
+        f32x16 acc = bias_acc(bias, h);
+        acc = MFMA(a0, f[0], acc);
+        acc = MFMA(a1, f[1], acc);
+        if (x != 7) store_tile<false>(acc, dst, pos, h);
     }
 }
 
@@ -109,134 +202,145 @@ __global__ void __launch_bounds__(NTHREADS, 2)
 k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* __restrict__ leaf_bb,
              const int32_t* __restrict__ leaf_info, int n, float* __restrict__ p_out, float* __restrict__ v_out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    uint8_t* bufX = lds;                       // conv1 output / scratch
+    uint8_t* bufX = lds;                       // conv1 output
     uint8_t* bufY = lds + ACT_BYTES;           // block input and output
-    float* sbias = reinterpret_cast<float*>(lds + 2 * ACT_BYTES);   // [3][32] + head bias [4]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int board0 = blockIdx.x * TB;
+    uint8_t* scr = lds + 2 * ACT_BYTES;
+    float* sbias = reinterpret_cast<float*>(scr + S_BIAS);
+    __bf16* hp = reinterpret_cast<__bf16*>(scr + S_HP);
+    __bf16* hv = reinterpret_cast<__bf16*>(scr + S_HV);
+    float* lg = reinterpret_cast<float*>(scr + S_LG);
+    float* vp = reinterpret_cast<float*>(scr + S_VP);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5;
 
-    // ---- zero both images, stage biases ------------------------------------------------
+    // zero everything once: padding cells and the k-padding of hp / hv are never written again
     {
         uint4* z = reinterpret_cast<uint4*>(lds);
-        for (int i = tid; i < 2 * ACT_BYTES / 16; i += NTHREADS) z[i] = make_uint4(0, 0, 0, 0);
-        if (tid < 100) sbias[tid] = reinterpret_cast<const float*>(blob + OFF_BIAS)[tid];
+        for (int i = tid; i < LDS_BYTES / 16; i += NTHREADS) z[i] = make_uint4(0, 0, 0, 0);
     }
     Weights w1, w2;
-    load_weights(w1, blob, 0, lane);           // stem first
-    load_weights(w2, blob, 2, lane);
+#pragma unroll
+    for (int s = 0; s < 18; ++s) {
+        w1.f[s] = frag_ptr(blob, OFF_WF, lane)[s * 64];
+        w2.f[s] = frag_ptr(blob, OFF_WF + 18 * 1024, lane)[s * 64];
+    }
+    __syncthreads();
+    if (tid < 100) sbias[tid] = reinterpret_cast<const float*>(blob + OFF_BIAS)[tid];
     __syncthreads();
 
-    // ---- input planes from bitboards: channel 0 = side to move, 1 = previous mover ------
-    {
-        const int b = tid >> 5, j = tid & 31;
-        const int gidx = board0 + b;
-        uint64_t nx = 0, pv = 0;
-        if (gidx < n) { nx = leaf_bb[2 * (size_t)gidx]; pv = leaf_bb[2 * (size_t)gidx + 1]; }
-        for (int cell = j; cell < 42; cell += 32) {
-            const int y = cell / 7, x = cell - 7 * y;
-            const int bit = x * 7 + y;
-            const int pos = b * NPOS + POS0 + y * 8 + x;
-            const uint32_t two = (((nx >> bit) & 1ull) ? 0x3F80u : 0u) | (((pv >> bit) & 1ull) ? 0x3F800000u : 0u);
-            *reinterpret_cast<uint32_t*>(bufX + act_addr(pos, 0)) = two;
+    const int ntiles = (n + TB - 1) / TB;
+    for (int bt = blockIdx.x; bt < ntiles; bt += gridDim.x) {
+        const int board0 = bt * TB;
+        // stem and tower: each wave works on its own two boards, no workgroup barrier needed
+        const uint8_t* sblob = blob;
+        asm volatile("" : "+s"(sblob));
+        stem(sblob, leaf_bb, board0, n, bufY, sbias, wave, lane);
+        for (int blk = 0; blk < num_blocks; ++blk) {
+            conv3x3<false>(w1, bufY, bufX, sbias + 32, wave, lane);
+            conv3x3<true>(w2, bufX, bufY, sbias + 64, wave, lane);
         }
-    }
-    __syncthreads();
 
-    // ---- stem, then the tower (one block, num_blocks times) -------------------------------
-    conv3x3<false>(w1, bufX, bufY, sbias, wave, lane);
-    load_weights(w1, blob, 1, lane);
-    __syncthreads();
-    for (int blk = 0; blk < num_blocks; ++blk) {
-        conv3x3<false>(w1, bufY, bufX, sbias + 32, wave, lane);
-        __syncthreads();
-        conv3x3<true>(w2, bufX, bufY, sbias + 64, wave, lane);
-        __syncthreads();
-    }
-
-    // ---- heads: both 1x1 convs as one 2-step MFMA; rows 0,1 = policy planes, 2 = value ------
-    float* hbuf = reinterpret_cast<float*>(bufX);          // [TB][3][48] f32 (bufX is free now)
-    {
-        const bf16x8* hf = reinterpret_cast<const bf16x8*>(blob + OFF_HF) + lane;
-        const bf16x8 a0 = hf[0], a1 = hf[64];
-        const int h = lane >> 5;
+        // Head weights are fetched here, per iteration: hoisted above the loop they would be
+        // spilled to scratch (the tower owns the register file).  The empty asm makes the
+        // pointer opaque so the loads stay below this point.
+        const uint8_t* hblob = blob;
+        asm volatile("" : "+s"(hblob));
+        // ---- 1x1 head convs as one 2-step MFMA: rows 0,1 = policy planes, row 2 = value plane
+        {
+            const bf16x8 a0 = frag_ptr(hblob, OFF_HF, lane)[0], a1 = frag_ptr(hblob, OFF_HF, lane)[64];
 #pragma unroll 1
-        for (int t = 0; t < TILES_PER_WAVE; ++t) {
-            const int R = (wave * TILES_PER_WAVE + t) * 32 + (lane & 31);
-            const int b = R / 48, o = R - b * 48;
-            const int pos = b * NPOS + POS0 + o;
+            for (int t = 0; t < TILES_PER_WAVE; ++t) {
+                const int R = (wave * TILES_PER_WAVE + t) * 32 + (lane & 31);
+                const int b = R / 48, o = R - b * 48;
+                const uint8_t* base = bufY + (b * BOARD_POS + POS0 + o) * PSTRIDE + h * 16;
+                f32x16 acc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+                acc = MFMA(a0, *reinterpret_cast<const bf16x8*>(base), acc);
+                acc = MFMA(a1, *reinterpret_cast<const bf16x8*>(base + 32), acc);
+                const int y = o >> 3, x = o & 7;
+                if (h == 0 && x != 7) {
+                    const int cell = y * 7 + x;
+                    hp[b * 96 + cell] = (__bf16)fmaxf(acc[0] + sbias[96], 0.0f);
+                    hp[b * 96 + 42 + cell] = (__bf16)fmaxf(acc[1] + sbias[97], 0.0f);
+                    hv[b * 48 + cell] = (__bf16)fmaxf(acc[2] + sbias[98], 0.0f);
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- value FC 42->256 (+ReLU) and 256->1: wave w owns hidden units 32w..32w+31
+        {
+            const int bcol = lane & 15;         // columns 16..31 duplicate boards 0..15 and are ignored
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(bufY + act_addr(pos, h));
-            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(bufY + act_addr(pos, 2 + h));
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc, 0, 0, 0);
-            if (h == 0) {
-                // all waves finished reading bufX before the last barrier; hbuf aliases it
-                hbuf[(b * 3 + 0) * 48 + o] = fmaxf(acc[0] + sbias[96], 0.0f);
-                hbuf[(b * 3 + 1) * 48 + o] = fmaxf(acc[1] + sbias[97], 0.0f);
-                hbuf[(b * 3 + 2) * 48 + o] = fmaxf(acc[2] + sbias[98], 0.0f);
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const bf16x8 a = frag_ptr(hblob, OFF_F1 + (wave * 3 + s) * 1024, lane)[0];
+                const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(hv + bcol * 48 + 16 * s + 8 * h);
+                acc = MFMA(a, bfr, acc);
+            }
+            const float* b1 = reinterpret_cast<const float*>(hblob + OFF_B1) + 32 * wave;
+            const float* w2v = reinterpret_cast<const float*>(hblob + OFF_W2) + 32 * wave;
+            float part = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                part = fmaf(fmaxf(acc[r] + b1[row], 0.0f), w2v[row], part);
+            }
+            part += __shfl_xor(part, 32);
+            if (lane < 32) vp[wave * 32 + lane] = part;
+        }
+        // ---- policy FC 84->42: waves 0,1 own cells 0..31 / 32..41
+        if (wave < 2) {
+            const int bcol = lane & 15;
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                const bf16x8 a = frag_ptr(hblob, OFF_PF + (wave * 6 + s) * 1024, lane)[0];
+                const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(hp + bcol * 96 + 16 * s + 8 * h);
+                acc = MFMA(a, bfr, acc);
+            }
+            if ((lane & 31) < 16) {
+                const float* bp = reinterpret_cast<const float*>(hblob + OFF_BP) + 32 * wave;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    lg[bcol * 64 + 32 * wave + row] = acc[r] + bp[row];
+                }
             }
         }
-    }
-    __syncthreads();
+        __syncthreads();
 
-    float* hid = reinterpret_cast<float*>(bufY);           // [256][TB] value hidden layer
-    if (tid < 256) {
-        // value head FC 42 -> 256 (+ReLU): thread = hidden unit, 16 boards at once
-        const float* w1t = reinterpret_cast<const float*>(blob + OFF_W1T);
-        float a[TB];
+        if (tid < TB * 8) {
+            // landing-cell gather (connectfour.py:56-71) + soft-max over legal columns (mcts.py:106)
+            const int b = tid >> 3, c = tid & 7;
+            const int gidx = board0 + b;
+            uint64_t occ = 0;
+            if (gidx < n) occ = leaf_bb[2 * (size_t)gidx] | leaf_bb[2 * (size_t)gidx + 1];
+            const int height = c < 7 ? __popcll((occ >> (7 * c)) & 0x3Full) : 6;
+            const bool legal = c < 7 && height < 6;
+            const float logit = legal ? lg[b * 64 + height * 7 + c] : -INFINITY;
+            float m = logit;
+            m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4));
+            const float e = legal ? __expf(logit - m) : 0.0f;
+            float sum = e;
+            sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
+            if (c < 7 && gidx < n) p_out[(size_t)gidx * 7 + c] = legal ? e / sum : 0.0f;
+        } else if (tid >= 256 && tid < 256 + TB) {
+            const int b = tid - 256, gidx = board0 + b;
+            float s = reinterpret_cast<const float*>(hblob + OFF_B2)[0];
 #pragma unroll
-        for (int b = 0; b < TB; ++b) a[b] = 0.0f;
-        for (int i = 0; i < 42; ++i) {
-            const float wv = w1t[i * 256 + tid];
-            const int o = (i / 7) * 8 + (i % 7);
-#pragma unroll
-            for (int b = 0; b < TB; ++b) a[b] = fmaf(wv, hbuf[(b * 3 + 2) * 48 + o], a[b]);
+            for (int w = 0; w < 8; ++w) s += vp[w * 32 + b];
+            if (gidx < n) v_out[gidx] = tanhf(s);
         }
-        const float b1 = reinterpret_cast<const float*>(blob + OFF_B1)[tid];
-        const float w2v = reinterpret_cast<const float*>(blob + OFF_W2)[tid];
-#pragma unroll
-        for (int b = 0; b < TB; ++b) hid[tid * TB + b] = fmaxf(a[b] + b1, 0.0f) * w2v;
-    } else if (tid < 256 + TB * 8) {
-        // policy head: FC 84 -> 42 evaluated only at the 7 landing cells, soft-max over legal columns
-        const int idx = tid - 256, b = idx >> 3, c = idx & 7;
-        const int gidx = board0 + b;
-        uint64_t occ = 0;
-        if (gidx < n) occ = leaf_bb[2 * (size_t)gidx] | leaf_bb[2 * (size_t)gidx + 1];
-        const int height = c < 7 ? __popcll((occ >> (7 * c)) & 0x3Full) : 6;
-        const bool legal = c < 7 && height < 6;
-        float logit = -INFINITY;
-        if (legal) {
-            const int cell = height * 7 + c;
-            const float* wrow = reinterpret_cast<const float*>(blob + OFF_WP) + cell * 84;
-            float s = reinterpret_cast<const float*>(blob + OFF_BP)[cell];
-            for (int ch = 0; ch < 2; ++ch)
-                for (int i = 0; i < 42; ++i)
-                    s = fmaf(wrow[ch * 42 + i], hbuf[(b * 3 + ch) * 48 + (i / 7) * 8 + (i % 7)], s);
-            logit = s;
-        }
-        float m = logit;
-        m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4));
-        const float e = legal ? __expf(logit - m) : 0.0f;
-        float sum = e;
-        sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
-        if (c < 7 && gidx < n) p_out[(size_t)gidx * 7 + c] = legal ? e / sum : 0.0f;
-    }
-    __syncthreads();
-    if (tid < TB * 16) {
-        // value head FC 256 -> 1 + tanh: 16 lanes per board
-        const int b = tid >> 4, part = tid & 15;
-        float s = 0.0f;
-        for (int u = part; u < 256; u += 16) s += hid[u * TB + b];
-        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
-        const int gidx = board0 + b;
-        if (part == 0 && gidx < n) v_out[gidx] = tanhf(s + reinterpret_cast<const float*>(blob + OFF_B2)[0]);
+        // the next iteration's stem writes bufY only; hp/hv/lg/vp are rewritten after >= 2 barriers
     }
     (void)leaf_info;
 }
 
-static thread_local std::string g_net_err;
 extern "C" {
 
 int az_c4net_blob_bytes(void) { return BLOB_BYTES; }
@@ -245,16 +349,17 @@ int az_c4net_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uint64_
                           const int32_t* leaf_info, int32_t n, float* p, float* v, void* stream) {
     if (n < 0 || num_blocks < 0 || (n && (!blob || !leaf_bb || !p || !v))) return -1;
     if (n == 0) return 0;
-    const int lds_bytes = 2 * ACT_BYTES + 128 * 4;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_c4net_bf16), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                lds_bytes) != hipSuccess)
+                                LDS_BYTES) != hipSuccess)
             return -2;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_c4net_bf16, dim3((n + TB - 1) / TB), dim3(NTHREADS), lds_bytes, (hipStream_t)stream, blob,
-                       (int)num_blocks, leaf_bb, leaf_info, (int)n, p, v);
+    int ntiles = (n + TB - 1) / TB;
+    int grid = ntiles < 256 ? ntiles : 256;      // one persistent workgroup per CU
+    hipLaunchKernelGGL(k_c4net_bf16, dim3(grid), dim3(NTHREADS), LDS_BYTES, (hipStream_t)stream, blob, (int)num_blocks,
+                       leaf_bb, leaf_info, (int)n, p, v);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

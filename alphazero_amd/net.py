@@ -25,20 +25,38 @@ def _fold_bn(w, bn, conv_bias=None):
     return w.double() * s.view(-1, 1, 1, 1), shift
 
 
-def _frags(w):
-    """Folded conv weight [32][32][3][3] -> MFMA A fragments [18][64][8] (bf16 as int16):
-    lane l holds Wt[co = l & 31][k = 8*(l >> 5) + j] of k-step s, with tap = s >> 1 and
-    input channel ci = 16*(s & 1) + 8*(l >> 5) + j."""
-    out = torch.zeros(18, 64, 8, dtype=torch.float32)
-    lane = torch.arange(64)
-    co, h = lane & 31, lane >> 5
-    for s in range(18):
-        tap = s >> 1
-        ty, tx = tap // 3, tap % 3
-        for j in range(8):
-            ci = 16 * (s & 1) + 8 * h + j
-            out[s, :, j] = w[co, ci, ty, tx]
-    return out.to(torch.bfloat16).view(torch.int16).numpy()
+def _bf16_bits(t):
+    return t.float().to(torch.bfloat16).view(torch.int16).numpy()
+
+
+def _lane_k(s):
+    """(row, k) held by element j of lane l in k-step s of a 32x32x16 MFMA A fragment:
+    row = l & 31, k = 16*s + 8*(l >> 5) + j.  Returns index tensors [64, 8]."""
+    lane = torch.arange(64).view(64, 1)
+    j = torch.arange(8).view(1, 8)
+    return (lane & 31).expand(64, 8), (16 * s + 8 * (lane >> 5) + j).expand(64, 8)
+
+
+def _gemm_frags(mat, ksteps):
+    """Dense matrix [rows <= 32][K] -> fragments [ksteps][64][8] of Wt[row][k], zero padded."""
+    rows, K = mat.shape
+    pad = torch.zeros(32, 16 * ksteps, dtype=torch.float64)
+    pad[:rows, :K] = mat
+    out = torch.zeros(ksteps, 64, 8, dtype=torch.float64)
+    for s in range(ksteps):
+        r, k = _lane_k(s)
+        out[s] = pad[r, k]
+    return _bf16_bits(out)
+
+
+def _conv_frags(w):
+    """Folded 3x3 conv weight [co <= 32][ci <= 32][3][3] -> [18][64][8]; k-step s covers tap s >> 1 and
+    input channels 16*(s & 1) .. +15, i.e. k = tap*32 + ci."""
+    co, ci = w.shape[:2]
+    mat = torch.zeros(32, 9 * 32, dtype=torch.float64)
+    for tap in range(9):
+        mat[:co, tap * 32:tap * 32 + ci] = w[:, :, tap // 3, tap % 3]
+    return _gemm_frags(mat, 18)
 
 
 def pack_c4_blob(model):
@@ -50,56 +68,60 @@ def pack_c4_blob(model):
         raise ValueError('fused kernel is for Connect Four (2x6x7 input)')
     lib = _lib.load()
     blob = np.zeros(lib.az_c4net_blob_bytes(), np.uint8)
+    off = 0
+
+    def put(arr):
+        nonlocal off
+        a = np.ascontiguousarray(arr).reshape(-1).view(np.uint8)
+        blob[off:off + a.size] = a
+        off += a.size
+
+    def putf(arr, pad_to=None):
+        a = np.ascontiguousarray(arr, np.float32).reshape(-1)
+        if pad_to:
+            a = np.concatenate([a, np.zeros(pad_to - a.size, np.float32)])
+        put(a)
+
     with torch.no_grad():
-        convs = []
-        w, b = _fold_bn(model._cbr[0].weight.cpu(), model._cbr[1].cpu())
-        convs.append((w, b))
-        blk = model._tower[0] if len(model._tower) else None
-        if blk is not None:
-            convs.append(_fold_bn(blk._c1.weight.cpu(), blk._bn1.cpu()))
-            convs.append(_fold_bn(blk._c2.weight.cpu(), blk._bn2.cpu()))
-        else:
-            z = torch.zeros(C_, C_, 3, 3, dtype=torch.float64)
-            convs += [(z, torch.zeros(C_, dtype=torch.float64))] * 2
-        off = 0
         bias = np.zeros((3, 32), np.float32)
-        for i, (w, b) in enumerate(convs):
-            wp = torch.zeros(32, 32, 3, 3, dtype=torch.float64)
-            wp[:w.shape[0], :w.shape[1]] = w
-            fr = _frags(wp.float())
-            blob[off:off + fr.nbytes] = fr.view(np.uint8).reshape(-1)
-            off += fr.nbytes
-            bias[i, :b.shape[0]] = b.float().numpy()
-        # heads: 1x1 convs -> rows 0,1 (policy) and 2 (value) of one 32x32 weight matrix
+        # stem: K index = tap*2 + plane
+        w, b = _fold_bn(model._cbr[0].weight.cpu(), model._cbr[1].cpu())
+        mat = torch.zeros(C_, 18, dtype=torch.float64)
+        for tap in range(9):
+            mat[:, 2 * tap] = w[:, 0, tap // 3, tap % 3]
+            mat[:, 2 * tap + 1] = w[:, 1, tap // 3, tap % 3]
+        put(_gemm_frags(mat, 2))
+        bias[0, :C_] = b.float().numpy()
+        if len(model._tower):
+            blk = model._tower[0]
+            for i, (cv, bn) in enumerate(((blk._c1, blk._bn1), (blk._c2, blk._bn2))):
+                w, b = _fold_bn(cv.weight.cpu(), bn.cpu())
+                put(_conv_frags(w))
+                bias[1 + i, :C_] = b.float().numpy()
+        else:
+            off += 2 * 18 * 1024
+        # heads: 1x1 convs -> rows 0,1 (policy planes) and 2 (value plane) of one [32][32] matrix
         ph, vh = model._policy_head, model._value_head
         wpol, bpol = _fold_bn(ph._cbr[0].weight.cpu(), ph._cbr[1].cpu(), ph._cbr[0].bias.cpu())
         wval, bval = _fold_bn(vh._cbr[0].weight.cpu(), vh._cbr[1].cpu())
-        wh = torch.zeros(32, 32, 3, 3, dtype=torch.float64)
-        wh[0:2, :C_, 1, 1] = wpol[:, :, 0, 0]
-        wh[2, :C_, 1, 1] = wval[0, :, 0, 0]
-        hf = _frags(wh.float())[8:10]            # centre tap = k-steps 8, 9
-        blob[off:off + hf.nbytes] = hf.view(np.uint8).reshape(-1)
-        off += hf.nbytes
-        blob[off:off + bias.nbytes] = bias.view(np.uint8).reshape(-1)
-        off += bias.nbytes
-        hb = np.array([bpol[0], bpol[1], bval[0], 0.0], np.float32)
-        blob[off:off + 16] = hb.view(np.uint8)
-        off += 16
-
-        def put(arr, pad_to=None):
-            nonlocal off
-            a = np.ascontiguousarray(arr, np.float32).reshape(-1)
-            if pad_to:
-                a = np.concatenate([a, np.zeros(pad_to - a.size, np.float32)])
-            blob[off:off + a.nbytes] = a.view(np.uint8)
-            off += a.nbytes
-        put(ph._fc.weight.cpu().numpy())                       # [42][84]
-        put(ph._fc.bias.cpu().numpy(), 44)
-        put(vh._fc[0].weight.cpu().numpy().T)                  # [42][256]
-        put(vh._fc[0].bias.cpu().numpy())
-        put(vh._fc[2].weight.cpu().numpy())                    # [256]
-        put(np.array([vh._fc[2].bias.item(), 0, 0, 0]))
-        assert off == blob.size, (off, blob.size)
+        mat = torch.zeros(3, 32, dtype=torch.float64)
+        mat[0:2, :C_] = wpol[:, :, 0, 0]
+        mat[2, :C_] = wval[0, :, 0, 0]
+        put(_gemm_frags(mat, 2))
+        # value FC1 [256][42]: 8 row tiles x 3 k-steps
+        w1 = vh._fc[0].weight.cpu().double()
+        for t in range(8):
+            put(_gemm_frags(w1[32 * t:32 * t + 32], 3))
+        # policy FC [42][84]: 2 row tiles x 6 k-steps
+        wp = ph._fc.weight.cpu().double()
+        put(_gemm_frags(wp[0:32], 6))
+        put(_gemm_frags(wp[32:42], 6))
+        putf(np.concatenate([bias.reshape(-1), [float(bpol[0]), float(bpol[1]), float(bval[0]), 0.0]]))
+        putf(ph._fc.bias.cpu().numpy(), 64)
+        putf(vh._fc[0].bias.cpu().numpy())
+        putf(vh._fc[2].weight.cpu().numpy())
+        putf(np.array([vh._fc[2].bias.item(), 0, 0, 0]))
+    assert off == blob.size, (off, blob.size)
     return blob
 
 
