@@ -50,7 +50,10 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define S_HV (S_HP + TB * 96 * 2)             // bf16 [TB][48] value plane
 #define S_LG (S_HV + TB * 48 * 2)             // float [TB][64] cell logits
 #define S_VP (S_LG + TB * 64 * 4)             // float [8][32] value partial sums per wave
-#define S_BYTES (S_VP + 8 * 32 * 4)
+#define S_TL (S_VP + 8 * 32 * 4)                // int [MAX_LIST] game index of each board this WG evaluates
+#define MAX_LIST 256
+#define S_WT (S_TL + MAX_LIST * 4)            // int [16] scan scratch
+#define S_BYTES (S_WT + 64)
 #define LDS_BYTES (2 * ACT_BYTES + S_BYTES)
 
 // blob layout (bytes); must match alphazero_amd/net.py
@@ -156,7 +159,7 @@ __device__ __forceinline__ void conv3x3(const Weights& w, const uint8_t* src, ui
 }
 
 // stem conv 2 -> C straight from bitboards: B[k][pos], k = tap*2 + plane (18 of 32 used)
-__device__ __forceinline__ void stem(const uint8_t* blob, const uint64_t* leaf_bb, int board0, int n, uint8_t* dst,
+__device__ __forceinline__ void stem(const uint8_t* blob, const uint64_t* leaf_bb, const int* games, uint8_t* dst,
                                      const float* bias, int wave, int lane) {
     const int h = lane >> 5;
     const bf16x8 a0 = frag_ptr(blob, OFF_SF, lane)[0], a1 = frag_ptr(blob, OFF_SF, lane)[64];
@@ -166,9 +169,9 @@ __device__ __forceinline__ void stem(const uint8_t* blob, const uint64_t* leaf_b
         const int b = R / 48, o = R - b * 48;
         const int pos = b * BOARD_POS + POS0 + o;
         const int y = o >> 3, x = o & 7;
-        const int gidx = board0 + b;
+        const int gidx = games[b];
         uint64_t bb[2] = {0, 0};
-        if (gidx < n) { bb[0] = leaf_bb[2 * (size_t)gidx] << 8; bb[1] = leaf_bb[2 * (size_t)gidx + 1] << 8; }
+        if (gidx >= 0) { bb[0] = leaf_bb[2 * (size_t)gidx] << 8; bb[1] = leaf_bb[2 * (size_t)gidx + 1] << 8; }
         // after the shift, cell (xx, yy) with xx in -1..7, yy in -1..6 is bit (xx+1)*7 + yy + 1;
         // out-of-board neighbours fall on guard bits, which are zero
         bf16x8 f[2];
@@ -227,13 +230,87 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
     if (tid < 100) sbias[tid] = reinterpret_cast<const float*>(blob + OFF_BIAS)[tid];
     __syncthreads();
 
-    const int ntiles = (n + TB - 1) / TB;
-    for (int bt = blockIdx.x; bt < ntiles; bt += gridDim.x) {
-        const int board0 = bt * TB;
-        // stem and tower: each wave works on its own two boards, no workgroup barrier needed
+    // ---- which leaves does this workgroup evaluate?  Only leaves that need the network
+    // (kind EVAL or ROOT in leaf_info) are packed, 16 per tile; tile t goes to workgroup
+    // t % gridDim.  Every workgroup scans the (L2-resident) leaf_info array itself, so the
+    // compaction costs no extra launch and no atomics, and the packing order is deterministic.
+    int* tlist = reinterpret_cast<int*>(scr + S_TL);
+    int* wtot = reinterpret_cast<int*>(scr + S_WT);
+    if (tid < MAX_LIST) tlist[tid] = -1;
+    __syncthreads();
+    int total;
+    if (!leaf_info) {
+        // dense mode: every leaf is evaluated, tile t = leaves [16t, 16t+16)
+        total = n;
+        int k = 0;
+        for (int tile = blockIdx.x; tile * TB < n && k * TB < MAX_LIST; tile += gridDim.x, ++k)
+            if (tid < TB && tile * TB + tid < n) tlist[k * TB + tid] = tile * TB + tid;
+    } else {
+        // thread t owns games [t*per, t*per + per); `per` is rounded up to a multiple of 4 so the
+        // kinds arrive as 16-byte loads, and the "needs eval" flags stay in a register mask
+        const int per = ((n + NTHREADS - 1) / NTHREADS + 3) & ~3;
+        const int g0 = tid * per;
+        unsigned long long mask = 0;           // up to 64 games per thread (n <= 32768)
+        {
+            for (int j = 0; j < per; j += 4) {
+                const int g = g0 + j;
+                int4 k4 = make_int4(0, 0, 0, 0);
+                if (g + 3 < n) k4 = *reinterpret_cast<const int4*>(leaf_info + g);
+                else {
+                    if (g < n) k4.x = leaf_info[g];
+                    if (g + 1 < n) k4.y = leaf_info[g + 1];
+                    if (g + 2 < n) k4.z = leaf_info[g + 2];
+                }
+                const int ks[4] = {k4.x & 0xFF, k4.y & 0xFF, k4.z & 0xFF, k4.w & 0xFF};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (ks[i] == AZ_LEAF_EVAL || ks[i] == AZ_LEAF_ROOT) mask |= 1ull << (j + i);
+            }
+        }
+        const int cnt = __popcll(mask);
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        int before = 0;
+        total = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const int t = wtot[w];
+            before += (w < wave) ? t : 0;
+            total += t;
+        }
+        // ranks [rank0, rank0 + cnt) belong to this thread; only the few threads whose ranks
+        // fall into one of this workgroup's tiles have anything to write
+        const int rank0 = before + incl - cnt;
+        const int ntl = (total + TB - 1) / TB;
+        int k = 0;
+        for (int tile = blockIdx.x; tile < ntl; tile += gridDim.x, ++k) {
+            const int lo = tile * TB;
+            if (rank0 + cnt <= lo || rank0 >= lo + TB || k * TB >= MAX_LIST) continue;
+            unsigned long long m = mask;
+            int rank = rank0;
+            while (m) {
+                const int j = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                if (rank >= lo && rank < lo + TB) tlist[k * TB + rank - lo] = g0 + j;
+                ++rank;
+            }
+        }
+    }
+    __syncthreads();
+
+    const int ntiles = (total + TB - 1) / TB;
+    int iter = 0;
+    for (int bt = blockIdx.x; bt < ntiles; bt += gridDim.x, ++iter) {
+        const int* games = tlist + iter * TB;
         const uint8_t* sblob = blob;
         asm volatile("" : "+s"(sblob));
-        stem(sblob, leaf_bb, board0, n, bufY, sbias, wave, lane);
+        stem(sblob, leaf_bb, games, bufY, sbias, wave, lane);
         for (int blk = 0; blk < num_blocks; ++blk) {
             conv3x3<false>(w1, bufY, bufX, sbias + 32, wave, lane);
             conv3x3<true>(w2, bufX, bufY, sbias + 64, wave, lane);
@@ -317,9 +394,9 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
         if (tid < TB * 8) {
             // landing-cell gather (connectfour.py:56-71) + soft-max over legal columns (mcts.py:106)
             const int b = tid >> 3, c = tid & 7;
-            const int gidx = board0 + b;
+            const int gidx = games[b];
             uint64_t occ = 0;
-            if (gidx < n) occ = leaf_bb[2 * (size_t)gidx] | leaf_bb[2 * (size_t)gidx + 1];
+            if (gidx >= 0) occ = leaf_bb[2 * (size_t)gidx] | leaf_bb[2 * (size_t)gidx + 1];
             const int height = c < 7 ? __popcll((occ >> (7 * c)) & 0x3Full) : 6;
             const bool legal = c < 7 && height < 6;
             const float logit = legal ? lg[b * 64 + height * 7 + c] : -INFINITY;
@@ -328,17 +405,16 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
             const float e = legal ? __expf(logit - m) : 0.0f;
             float sum = e;
             sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
-            if (c < 7 && gidx < n) p_out[(size_t)gidx * 7 + c] = legal ? e / sum : 0.0f;
+            if (c < 7 && gidx >= 0) p_out[(size_t)gidx * 7 + c] = legal ? e / sum : 0.0f;
         } else if (tid >= 256 && tid < 256 + TB) {
-            const int b = tid - 256, gidx = board0 + b;
+            const int b = tid - 256, gidx = games[b];
             float s = reinterpret_cast<const float*>(hblob + OFF_B2)[0];
 #pragma unroll
             for (int w = 0; w < 8; ++w) s += vp[w * 32 + b];
-            if (gidx < n) v_out[gidx] = tanhf(s);
+            if (gidx >= 0) v_out[gidx] = tanhf(s);
         }
         // the next iteration's stem writes bufY only; hp/hv/lg/vp are rewritten after >= 2 barriers
     }
-    (void)leaf_info;
 }
 
 extern "C" {
@@ -358,6 +434,7 @@ int az_c4net_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uint64_
     }
     int ntiles = (n + TB - 1) / TB;
     int grid = ntiles < 256 ? ntiles : 256;      // one persistent workgroup per CU
+    if (n > 32768) return -4;                    // the in-kernel packing handles up to 64 leaves per thread
     hipLaunchKernelGGL(k_c4net_bf16, dim3(grid), dim3(NTHREADS), LDS_BYTES, (hipStream_t)stream, blob, (int)num_blocks,
                        leaf_bb, leaf_info, (int)n, p, v);
     return hipGetLastError() == hipSuccess ? 0 : -3;

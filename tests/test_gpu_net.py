@@ -60,3 +60,31 @@ def test_fused_bf16_forward_matches_torch_fp32(blocks, ch, n):
     assert (p - pref).abs().max().item() < 5e-3, (p - pref).abs().max().item()
     assert (v - vref.reshape(-1)).abs().max().item() < 5e-3, (v - vref.reshape(-1)).abs().max().item()
     print('max |dp|', (p - pref).abs().max().item(), 'max |dv|', (v - vref.reshape(-1)).abs().max().item())
+
+
+def test_fused_forward_packs_only_leaves_that_need_eval():
+    """Leaves whose kind is NONE / TERMINAL are skipped (their output rows are left alone);
+    the packed evaluation of the others equals the dense evaluation row for row."""
+    from alphazero_amd import engine as E
+    from alphazero_amd.models import AlphaZeroC4
+    from alphazero_amd.net import FusedC4Net
+    torch.manual_seed(3)
+    model = AlphaZeroC4(2, 32).eval()
+    n = 3000
+    hists = _random_positions(n, 21)
+    bb, nm = E.positions_from_history(1, hists)
+    legal, _, _ = E.game_query(1, bb, nm)
+    net = FusedC4Net.from_module(model, 'cuda')
+    dense_p, dense_v = net(bb, ((legal << 16) | 1).to(torch.int32))
+    dense_p, dense_v = dense_p.clone(), dense_v.clone()
+    rng = np.random.RandomState(4)
+    for frac in (0.0, 0.03, 0.5, 0.83, 1.0):
+        kind = torch.from_numpy(rng.choice([0, 1, 2, 3], size=n, p=[(1 - frac) / 2, frac * 0.9, (1 - frac) / 2, frac * 0.1])
+                                .astype(np.int32)).cuda()
+        info = ((legal << 16) | kind).to(torch.int32)
+        net._p.fill_(-7.0)
+        net._v.fill_(-7.0)
+        p, v = net(bb, info)
+        act = (kind == 1) | (kind == 3)
+        assert torch.equal(p[act], dense_p[act]) and torch.equal(v[act], dense_v[act])
+        assert torch.all(p[~act] == -7.0) and torch.all(v[~act] == -7.0)

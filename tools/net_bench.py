@@ -28,15 +28,22 @@ info = ((legal << 16) | 1).to(torch.int32)
 for blocks in [int(b) for b in args.blocks.split(',')]:
     torch.manual_seed(0)
     net = FusedC4Net.from_module(AlphaZeroC4(blocks, args.ch).eval(), 'cuda')
-    for _ in range(5):
-        net(bb, info)
-    torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(args.iters):
-        net(bb, info)
-    b.record()
-    torch.cuda.synchronize()
-    us = a.elapsed_time(b) * 1e3 / args.iters
     flops = args.n * (2 * blocks * 2 * 9 * args.ch * args.ch * 42 + 2 * 9 * 2 * args.ch * 42)
-    print(f'blocks={blocks} ch={args.ch} n={args.n}: {us:.1f} us/launch, {flops / us / 1e6:.1f} TFLOP/s')
+    # interleaved rounds in one process: dense (no packing scan) vs packed with every leaf active
+    res = {'dense': [], 'packed': []}
+    for rnd in range(5):
+        for name, inf in (('dense', None), ('packed', info)):
+            for _ in range(3):
+                net(bb, inf)
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(args.iters):
+                net(bb, inf)
+            b.record()
+            torch.cuda.synchronize()
+            res[name].append(a.elapsed_time(b) * 1e3 / args.iters)
+    for name, v in res.items():
+        us = sorted(v)[len(v) // 2]
+        print(f'blocks={blocks} ch={args.ch} n={args.n} {name}: median {us:.1f} us (min {min(v):.1f}), '
+              f'{flops / us / 1e6:.1f} TFLOP/s')
