@@ -22,6 +22,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 
@@ -569,6 +570,212 @@ k_choose(Dev E, const double* u_in, int32_t* out_action, int32_t* out_nedges, ui
 }
 
 // ---------------------------------------------------------------------------
+// packed search kernels: GS lanes per game (8 for Connect Four, 16 for tic-tac-toe), so a
+// wavefront runs 64/GS trees at once.  A node's A+1 records map onto the group's lanes, the
+// arg-max is a DPP butterfly inside the group, and every "uniform per tree" value lives
+// replicated in the group's lanes.  Trees of one wave descend in lock-step; a group whose
+// simulation has reached its leaf idles (exec-masked) until the deepest one is done.  Compared
+// with a whole wavefront per tree this issues 64/GS times fewer vector instructions, which is
+// what bounded the one-tree-per-wave form (its memory latency was already hidden by 8 waves
+// per SIMD).
+// ---------------------------------------------------------------------------
+template <int GS>
+struct Grp {
+    static constexpr int GPW = 64 / GS;    // games per wave
+    __device__ static __forceinline__ uint32_t bcast(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, GS); }
+    __device__ static __forceinline__ double gmax(double x) {
+        x = fmax(x, dpp_f64<0xB1>(x));    // quad_perm [1,0,3,2]
+        x = fmax(x, dpp_f64<0x4E>(x));    // quad_perm [2,3,0,1]
+        x = fmax(x, dpp_f64<0x141>(x));   // row_half_mirror
+        if (GS >= 16) x = fmax(x, dpp_f64<0x140>(x));  // row_mirror
+        return x;
+    }
+    // predicate bits of this lane's group, bit i = lane (group base + i), first 16 lanes only
+    __device__ static __forceinline__ uint32_t gballot(bool p) {
+        const unsigned long long m = __ballot(p);
+        return (uint32_t)(m >> (lane_id() & ~(GS - 1))) & (GS >= 16 ? 0xFFFFu : ((1u << GS) - 1u));
+    }
+};
+
+// mcts.py:119-134 for the group's tree; path[] is this game's row of the block's LDS path stack
+template <class GM, int GS>
+__device__ __forceinline__ void select_leaf_g(const Dev& E, const uint4* pool, uint32_t root, uint64_t& nx,
+                                              uint64_t& pv, int& nm, uint32_t* path, int sub, int& kind,
+                                              int& depth, float& vterm, uint32_t& steps) {
+    constexpr int AS = GM::A + 1;
+    static_assert(AS <= GS, "group too small for this game");
+    using G_ = Grp<GS>;
+    kind = AZ_LEAF_NONE; depth = 0; vterm = 0.0f;
+    uint32_t node = root;
+    bool active = root != AZ_NO_NODE && GM::winner(nx, pv, nm) == AZ_W_NONE;
+    while (active) {
+        uint4 e = make_uint4(0u, 0u, 0u, AZ_NO_NODE);
+        if (sub < AS) e = pool[(size_t)node * AS + sub];
+        const int n_edges = (int)G_::bcast(e.x, AS - 1);
+        const uint32_t Ns = G_::bcast(e.y, AS - 1);
+        double cs, sq;
+        lut_lookup(E, Ns, cs, sq);
+        const bool act = sub < n_edges;
+        double score = -INFINITY;
+        if (act) score = puct_score(e.x, __uint_as_float(e.y), __uint_as_float(e.z), cs, sq);
+        const double mx = G_::gmax(score);
+        const uint32_t hit = G_::gballot(act && score == mx);
+        const int slot = __ffs((int)hit) - 1;                          // np.argmax: first maximum
+        const uint32_t child = G_::bcast(e.w, slot);
+        const int action = az_nth_set_bit(GM::legal(nx, pv), slot);    // mcts.py:126
+        if (sub == 0) path[depth] = (node << 4) | (uint32_t)slot;
+        depth += 1;
+        steps += 1;
+        GM::play(nx, pv, nm, action);
+        const int w = GM::winner(nx, pv, nm);
+        if (w != AZ_W_NONE) {                                          // mcts.py:131-134
+            kind = AZ_LEAF_TERMINAL;
+            vterm = az_terminal_value_prev(w, nm);
+            active = false;
+        } else if (child == AZ_NO_NODE) {                              // mcts.py:135-138
+            kind = AZ_LEAF_EVAL;
+            active = false;
+        } else {
+            node = child;
+        }
+    }
+}
+
+template <class GM, int GS>
+__device__ __forceinline__ uint32_t expand_node_g(const Dev& E, uint4* pool, uint32_t& alloc, uint64_t nx,
+                                                  uint64_t pv, const float* p, uint32_t& err, int sub) {
+    constexpr int AS = GM::A + 1;
+    if (alloc >= (uint32_t)E.cap) { err |= 1u; return AZ_NO_NODE; }
+    const uint32_t idx = alloc;
+    alloc += 1;
+    const uint32_t legal = GM::legal(nx, pv);
+    const int n_edges = az_popc32(legal);
+    if (sub < AS) {
+        uint4 rec = make_uint4(0u, 0u, 0u, AZ_NO_NODE);
+        if (sub < n_edges) {
+            const int a = az_nth_set_bit(legal, sub);
+            const float pr = p ? p[a] : 1.0f / (float)n_edges;
+            rec.z = __float_as_uint(pr);
+        }
+        if (sub == AS - 1) rec = make_uint4((uint32_t)n_edges, 0u, 0u, 0u);
+        pool[(size_t)idx * AS + sub] = rec;
+    }
+    return idx;
+}
+
+// mcts.py:147-158: the group's lanes take path levels sub, sub+GS, ... (levels are distinct nodes)
+template <class GM, int GS>
+__device__ __forceinline__ void backup_g(uint4* pool, int depth, const uint32_t* path, float v_leaf_edge, int sub) {
+    constexpr int AS = GM::A + 1;
+    for (int d = sub; d < depth; d += GS) {
+        const uint32_t ent = path[d];
+        const uint32_t node = ent >> 4, slot = ent & 15u;
+        const float v = ((depth - 1 - d) & 1) ? -v_leaf_edge : v_leaf_edge;
+        uint2* ep = reinterpret_cast<uint2*>(&pool[(size_t)node * AS + slot]);
+        uint2 nw = *ep;
+        nw.x += 1u;
+        nw.y = __float_as_uint(__uint_as_float(nw.y) + v);
+        *ep = nw;
+        uint32_t* ns = reinterpret_cast<uint32_t*>(&pool[(size_t)node * AS + AS - 1]) + 1;
+        *ns += 1u;
+    }
+}
+
+#define GROUP_PROLOGUE                                                                   \
+    constexpr int GPW = 64 / GS;                                                         \
+    __shared__ uint32_t lds_path[WAVES_PER_BLOCK * GPW][PATH_LEN];                       \
+    const int lane = lane_id(), sub = lane & (GS - 1);                                   \
+    const int gl = (int)(threadIdx.x >> 6) * GPW + lane / GS;                            \
+    const int g = (int)blockIdx.x * (WAVES_PER_BLOCK * GPW) + gl;                        \
+    if (g >= E.G) return;                                                                \
+    Slot* s = E.slots + g;                                                               \
+    uint4* pool = E.pool + (size_t)g * E.cap * (GM::A + 1);                              \
+    uint32_t* path = lds_path[gl];
+
+// mcts.py:119-158, one simulation per game per launch (see k_sim_step), GS lanes per game
+template <class GM, int GS, bool DO_EXPAND, bool DO_SELECT>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+k_sim_step_p(Dev E, const float* p, const float* v, uint64_t* leaf_bb, int32_t* leaf_info) {
+    GROUP_PROLOGUE
+    uint32_t alloc = s->alloc, err = s->err;
+    const uint32_t root = s->root;
+    uint32_t sims = 0, evals = 0, steps = 0;
+    int kind = s->leaf_kind;
+
+    if (DO_EXPAND && kind == AZ_LEAF_EVAL) {
+        const int depth = s->leaf_depth;
+        for (int d = sub; d < depth; d += GS) path[d] = s->path[d];
+        const uint32_t idx = expand_node_g<GM, GS>(E, pool, alloc, s->leaf_nx, s->leaf_pv, p + (size_t)g * GM::A, err, sub);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");        // path[] written by other lanes of the group
+        const uint32_t last = path[depth - 1];
+        if (idx != AZ_NO_NODE && sub == 0)
+            reinterpret_cast<uint32_t*>(&pool[(size_t)(last >> 4) * (GM::A + 1) + (last & 15u)])[3] = idx;
+        backup_g<GM, GS>(pool, depth, path, -v[g], sub);               // mcts.py:144
+        sims += 1; evals += 1;
+        kind = AZ_LEAF_NONE;
+    }
+    if (DO_EXPAND && DO_SELECT) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+
+    if (DO_SELECT) {
+        uint64_t nx = s->nx, pv = s->pv;
+        int nm = s->nm, depth;
+        float vterm;
+        select_leaf_g<GM, GS>(E, pool, root, nx, pv, nm, path, sub, kind, depth, vterm, steps);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        if (kind == AZ_LEAF_TERMINAL) {
+            backup_g<GM, GS>(pool, depth, path, vterm, sub);
+            sims += 1;
+        } else if (kind == AZ_LEAF_EVAL) {
+            for (int d = sub; d < depth; d += GS) s->path[d] = path[d];
+        }
+        if (sub == 0) {
+            s->leaf_depth = depth; s->leaf_nx = nx; s->leaf_pv = pv; s->leaf_nm = nm;
+            leaf_bb[2 * (size_t)g] = nx; leaf_bb[2 * (size_t)g + 1] = pv;
+            leaf_info[g] = kind | (nm << 8) | ((int)GM::legal(nx, pv) << 16);
+        }
+    }
+    if (sub == 0) {
+        s->leaf_kind = kind; s->alloc = alloc; s->err = err;
+        s->move_sims += sims; s->st_sims += sims; s->st_evals += evals; s->st_steps += steps;
+    }
+}
+
+// num_sims whole simulations per game in one launch, UniformModel evaluated in place
+template <class GM, int GS>
+__global__ void __launch_bounds__(BLOCK_THREADS) k_run_uniform_p(Dev E, int num_sims) {
+    GROUP_PROLOGUE
+    uint32_t alloc = s->alloc, err = s->err;
+    const uint32_t root = s->root;
+    const uint64_t nx0 = s->nx, pv0 = s->pv;
+    const int nm0 = s->nm;
+    uint32_t sims = 0, evals = 0, steps = 0;
+    if (root == AZ_NO_NODE) return;
+    for (int it = 0; it < num_sims; ++it) {
+        uint64_t nx = nx0, pv = pv0;
+        int nm = nm0, depth, kind;
+        float vterm;
+        select_leaf_g<GM, GS>(E, pool, root, nx, pv, nm, path, sub, kind, depth, vterm, steps);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        if (kind == AZ_LEAF_EVAL) {
+            const uint32_t idx = expand_node_g<GM, GS>(E, pool, alloc, nx, pv, nullptr, err, sub);
+            const uint32_t last = path[depth - 1];
+            if (idx != AZ_NO_NODE && sub == 0)
+                reinterpret_cast<uint32_t*>(&pool[(size_t)(last >> 4) * (GM::A + 1) + (last & 15u)])[3] = idx;
+            backup_g<GM, GS>(pool, depth, path, -0.0f, sub);           // v = 0, then v *= -1
+            evals += 1;
+        } else if (kind == AZ_LEAF_TERMINAL) {
+            backup_g<GM, GS>(pool, depth, path, vterm, sub);
+        }
+        sims += 1;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");        // own stores before next select's loads
+    }
+    if (sub == 0) {
+        s->alloc = alloc; s->err = err; s->leaf_kind = AZ_LEAF_NONE;
+        s->move_sims += sims; s->st_sims += sims; s->st_evals += evals; s->st_steps += steps;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // stateless bulk kernels (one thread per position)
 // ---------------------------------------------------------------------------
 template <class GM>
@@ -666,6 +873,22 @@ __global__ void k_ucb(Dev E, const uint32_t* N, const float* W, const float* P, 
 // host side
 // ---------------------------------------------------------------------------
 static inline dim3 wave_grid(int G) { return dim3((G + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK); }
+// lanes per game of the packed search kernels: the smallest power of two that holds a node
+// (A+1 records) issues the fewest vector instructions; larger groups put more wavefronts on each
+// SIMD to hide memory latency.  AZ_GROUP_SIZE (8/16/32/64) overrides the default for tuning.
+template <class GM> struct GroupSize { static constexpr int min_value = GM::A + 1 <= 8 ? 8 : 16; };
+static int group_size_for(int min_gs, int G) {
+    static int env = -1;
+    if (env < 0) { const char* v = getenv("AZ_GROUP_SIZE"); env = v ? atoi(v) : 0; }
+    (void)G;
+    int gs = env ? env : min_gs;
+    if (gs != 8 && gs != 16 && gs != 32 && gs != 64) gs = 16;
+    return gs < min_gs ? min_gs : gs;
+}
+static inline dim3 group_grid(int G, int gs) {
+    const int per_block = WAVES_PER_BLOCK * (64 / gs);
+    return dim3((G + per_block - 1) / per_block);
+}
 #define LAUNCH_CHECK() do { hipError_t _e = hipGetLastError(); if (_e != hipSuccess) return fail("kernel launch", _e); } while (0)
 #define DISPATCH_GAME(game, ...)                                   \
     do {                                                           \
@@ -783,17 +1006,26 @@ int az_apply_root(az_engine* e, const float* p, const double* eta, void* stream)
 
 int az_select(az_engine* e, uint64_t* leaf_bb, int32_t* leaf_info, void* stream) {
     if (!e || !leaf_bb || !leaf_info) return fail("null argument");
-    DISPATCH_GAME(e->cfg.game, hipLaunchKernelGGL((k_sim_step<GM, false, true>), wave_grid(e->d.G), dim3(BLOCK_THREADS), 0,
-                                                  (hipStream_t)stream, e->d, (const float*)nullptr, (const float*)nullptr,
-                                                  leaf_bb, leaf_info));
+    DISPATCH_GAME(e->cfg.game, { const int gs_ = group_size_for(GroupSize<GM>::min_value, e->d.G); const dim3 gr_ = group_grid(e->d.G, gs_);
+  switch (gs_) {
+    case 8: if constexpr (8 >= GroupSize<GM>::min_value) hipLaunchKernelGGL((k_sim_step_p<GM, 8, false, true>), gr_, dim3(BLOCK_THREADS), 0, (hipStream_t)stream, e->d, (const float*)nullptr, (const float*)nullptr, leaf_bb, leaf_info); break;
+    case 16: if constexpr (16 >= GroupSize<GM>::min_value) hipLaunchKernelGGL((k_sim_step_p<GM, 16, false, true>), gr_, dim3(BLOCK_THREADS), 0, (hipStream_t)stream, e->d, (const float*)nullptr, (const float*)nullptr, leaf_bb, leaf_info); break;
+    case 32: if constexpr (32 >= GroupSize<GM>::min_value) hipLaunchKernelGGL((k_sim_step_p<GM, 32, false, true>), gr_, dim3(BLOCK_THREADS), 0, (hipStream_t)stream, e->d, (const float*)nullptr, (const float*)nullptr, leaf_bb, leaf_info); break;
+    case 64: if constexpr (64 >= GroupSize<GM>::min_value) hipLaunchKernelGGL((k_sim_step_p<GM, 64, false, true>), gr_, dim3(BLOCK_THREADS), 0, (hipStream_t)stream, e->d, (const float*)nullptr, (const float*)nullptr, leaf_bb, leaf_info); break;
+  } });
     LAUNCH_CHECK();
     return 0;
 }
 
 int az_expand_backup(az_engine* e, const float* p, const float* v, void* stream) {
     if (!e || !p || !v) return fail("null argument");
-    DISPATCH_GAME(e->cfg.game, hipLaunchKernelGGL((k_sim_step<GM, true, false>), wave_grid(e->d.G), dim3(BLOCK_THREADS), 0,
-                                                  (hipStream_t)stream, e->d, p, v, (uint64_t*)nullptr, (int32_t*)nullptr));
+    DISPATCH_GAME(e->cfg.game, { const int gs_ = group_size_for(GroupSize<GM>::min_value, e->d.G); const dim3 gr_ = group_grid(e->d.G, gs_);
+  switch (gs_) {
+    case 8: if constexpr (8 >= GroupSize<GM>::min_value) hipLaunchKernelGGL((k_sim_step_p<GM, 8, true, false>), gr_, dim3(BLOCK_THREADS), 0, (hipStream_t)stream, e->d, p, v, (uint64_t*)nullptr, (int32_t*)nullptr); break;
+    case 16: if constexpr (16 >= GroupSize<GM>::min_value) hipLaunchKernelGGL((k_sim_step_p<GM, 16, true, false>), gr_, dim3(BLOCK_THREADS), 0, (hipStream_t)stream, e->d, p, v, (uint64_t*)nullptr, (int32_t*)nullptr); break;
+    case 32: if constexpr (32 >= GroupSize<GM>::min_value) hipLaunchKernelGGL((k_sim_step_p<GM, 32, true, false>), gr_, dim3(BLOCK_THREADS), 0, (hipStream_t)stream, e->d, p, v, (uint64_t*)nullptr, (int32_t*)nullptr); break;
+    case 64: if constexpr (64 >= GroupSize<GM>::min_value) hipLaunchKernelGGL((k_sim_step_p<GM, 64, true, false>), gr_, dim3(BLOCK_THREADS), 0, (hipStream_t)stream, e->d, p, v, (uint64_t*)nullptr, (int32_t*)nullptr); break;
+  } });
     LAUNCH_CHECK();
     return 0;
 }
@@ -802,16 +1034,26 @@ int az_sim_step(az_engine* e, const float* p, const float* v, uint64_t* leaf_bb,
     if (!e || !leaf_bb || !leaf_info) return fail("null argument");
     if (!p) return az_select(e, leaf_bb, leaf_info, stream);
     if (!v) return fail("v is required with p");
-    DISPATCH_GAME(e->cfg.game, hipLaunchKernelGGL((k_sim_step<GM, true, true>), wave_grid(e->d.G), dim3(BLOCK_THREADS), 0,
-                                                  (hipStream_t)stream, e->d, p, v, leaf_bb, leaf_info));
+    DISPATCH_GAME(e->cfg.game, { const int gs_ = group_size_for(GroupSize<GM>::min_value, e->d.G); const dim3 gr_ = group_grid(e->d.G, gs_);
+  switch (gs_) {
+    case 8: if constexpr (8 >= GroupSize<GM>::min_value) hipLaunchKernelGGL((k_sim_step_p<GM, 8, true, true>), gr_, dim3(BLOCK_THREADS), 0, (hipStream_t)stream, e->d, p, v, leaf_bb, leaf_info); break;
+    case 16: if constexpr (16 >= GroupSize<GM>::min_value) hipLaunchKernelGGL((k_sim_step_p<GM, 16, true, true>), gr_, dim3(BLOCK_THREADS), 0, (hipStream_t)stream, e->d, p, v, leaf_bb, leaf_info); break;
+    case 32: if constexpr (32 >= GroupSize<GM>::min_value) hipLaunchKernelGGL((k_sim_step_p<GM, 32, true, true>), gr_, dim3(BLOCK_THREADS), 0, (hipStream_t)stream, e->d, p, v, leaf_bb, leaf_info); break;
+    case 64: if constexpr (64 >= GroupSize<GM>::min_value) hipLaunchKernelGGL((k_sim_step_p<GM, 64, true, true>), gr_, dim3(BLOCK_THREADS), 0, (hipStream_t)stream, e->d, p, v, leaf_bb, leaf_info); break;
+  } });
     LAUNCH_CHECK();
     return 0;
 }
 
 int az_run_sims_uniform(az_engine* e, int32_t num_sims, void* stream) {
     if (!e || num_sims < 0) return fail("bad argument");
-    DISPATCH_GAME(e->cfg.game, hipLaunchKernelGGL((k_run_uniform<GM>), wave_grid(e->d.G), dim3(BLOCK_THREADS), 0,
-                                                  (hipStream_t)stream, e->d, (int)num_sims));
+    DISPATCH_GAME(e->cfg.game, { const int gs_ = group_size_for(GroupSize<GM>::min_value, e->d.G); const dim3 gr_ = group_grid(e->d.G, gs_);
+  switch (gs_) {
+    case 8: if constexpr (8 >= GroupSize<GM>::min_value) hipLaunchKernelGGL((k_run_uniform_p<GM, 8>), gr_, dim3(BLOCK_THREADS), 0, (hipStream_t)stream, e->d, (int)num_sims); break;
+    case 16: if constexpr (16 >= GroupSize<GM>::min_value) hipLaunchKernelGGL((k_run_uniform_p<GM, 16>), gr_, dim3(BLOCK_THREADS), 0, (hipStream_t)stream, e->d, (int)num_sims); break;
+    case 32: if constexpr (32 >= GroupSize<GM>::min_value) hipLaunchKernelGGL((k_run_uniform_p<GM, 32>), gr_, dim3(BLOCK_THREADS), 0, (hipStream_t)stream, e->d, (int)num_sims); break;
+    case 64: if constexpr (64 >= GroupSize<GM>::min_value) hipLaunchKernelGGL((k_run_uniform_p<GM, 64>), gr_, dim3(BLOCK_THREADS), 0, (hipStream_t)stream, e->d, (int)num_sims); break;
+  } });
     LAUNCH_CHECK();
     return 0;
 }

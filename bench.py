@@ -43,8 +43,10 @@ def trunk_flops_per_leaf(blocks, ch, cells=42, planes=2):
 
 def cpu_baseline(model_name, sims, seconds, workers):
     """The CPU oracle (oracle/az_oracle.c, the restatement of the reference's algorithm)
-    playing whole games, one independent single-game worker per core as `train.py -n N`
-    does (alphazero/train.py:131-134).  Bounded sample: each worker plays for ~`seconds`."""
+    playing self-play moves, one independent single-game worker per core as `train.py -n N`
+    does (alphazero/train.py:131-134), one network call per leaf with one torch thread per
+    worker (alphazero/mcts.py:94-107).  Bounded sample: each worker plays whole moves until
+    `seconds` have passed."""
     import multiprocessing as mp
     ctx = mp.get_context('spawn')
     with ctx.Pool(workers) as pool:
@@ -56,10 +58,13 @@ def cpu_baseline(model_name, sims, seconds, workers):
 
 
 def _cpu_worker(model_name, sims, seconds, wid):
+    os.environ['OMP_NUM_THREADS'] = '1'
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import ctypes as C
     import numpy as np
     import oracle as orc
     from alphazero_amd.engine import make_puct_lut
+    L = orc.lib()
     lut = orc.make_lut_array(make_puct_lut(sims * 42 + 64))
     cfg = orc.make_config(orc.C4, sims, 4, True, lut)
     if model_name == 'uniform':
@@ -72,7 +77,7 @@ def _cpu_worker(model_name, sims, seconds, wid):
         torch.manual_seed(0)
         net = AlphaZeroC4(blocks, ch).eval()
 
-        def fn(game, hist, valid):          # one net call per leaf, batch 1 (mcts.py:94-107)
+        def fn(game, hist, valid):
             x = torch.from_numpy(orc.render(game, hist)[None])
             m = torch.zeros(1, 7, dtype=torch.bool)
             m[0, valid] = True
@@ -81,27 +86,44 @@ def _cpu_worker(model_name, sims, seconds, wid):
                 p = torch.softmax(lg[m], 0)
             return p.numpy(), float(v[0, 0])
         ev = orc.eval_from_python(fn)
+    rng = orc.Rng()
+    L.orc_rng_seed(C.byref(rng), 1000 + wid)
+    dir_cb = C.cast(L.orc_rng_dirichlet, orc.DIRICHLET_FN)
     t0 = time.time()
     pos = sim = 0
-    seed = 1000 + wid
     while time.time() - t0 < seconds:
-        st = orc.Stats()
-        rec = orc.play_game_builtin_rng(cfg, ev, seed, st)
-        seed += 100
-        pos += rec.num_moves
-        sim += st.sims
+        # selfplay.py:12-42, one move at a time so the sample can stop on a move boundary
+        hist, tree = [], orc.Node()
+        top = tree
+        while not orc.terminal(orc.C4, hist) and time.time() - t0 < seconds:
+            st = orc.Stats()
+            h, n = orc._hist(hist)
+            L.orc_run_mcts(C.byref(cfg), h, n, tree.ptr, ev, None, dir_cb, C.byref(rng), C.byref(st))
+            if len(hist) < 4:
+                ai = tree.sample_action(L.orc_rng_uniform(C.byref(rng)))
+            else:
+                ai = tree.greedy_action()
+            hist.append(orc.valid_actions(orc.C4, hist)[ai])
+            tree = tree.traverse(ai)
+            tree.kill_siblings()
+            pos += 1
+            sim += st.sims
+        del top
     return pos, sim, time.time() - t0
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=4)
-    ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--model', default='uniform', choices=['uniform', 'c4_6x32', 'c4_10x128'])
+    ap.add_argument('--steps', type=int, default=6)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--model', default='c4_6x32', choices=['uniform', 'c4_6x32'])
     ap.add_argument('--net-impl', default='hip', choices=['torch', 'hip'])
     ap.add_argument('--games', type=int, default=8192)
     ap.add_argument('--sims', type=int, default=800)
+    ap.add_argument('--preroll', type=int, default=24,
+                    help='untimed lock-step moves played before warmup so that the game slots are spread '
+                         'over opening / middle game / endgame as in a long-running job')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     args = ap.parse_args()
@@ -130,7 +152,7 @@ def main():
     if args.model != 'uniform':
         from alphazero_amd.models import AlphaZeroC4
         from alphazero_amd.mcts import evaluate_leaves
-        blocks, ch = (6, 32) if args.model == 'c4_6x32' else (10, 128)
+        blocks, ch = 6, 32                      # alphazero/config/connectfour.yaml:4-9
         torch.manual_seed(0)
         net = AlphaZeroC4(blocks, ch).to(dev).eval()
         flat = torch.nn.utils.parameters_to_vector(net.parameters()).detach()
@@ -141,20 +163,22 @@ def main():
         else:
             evaluate = lambda bb, info: evaluate_leaves(eng.game, net, bb, info)
 
-    ev_start = torch.cuda.Event(enable_timing=True)
-    ev_end = torch.cuda.Event(enable_timing=True)
-    kern_ms = []       # per-launch duration of the dominant kernel, HIP events
+    net_ev, tree_ev = [], []       # (start, end) HIP event pairs on the launch stream
 
-    def one_step(timed):
+    def timed(fn, sink, on):
+        if not on:
+            return fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        r = fn()
+        b.record()
+        sink.append((a, b))
+        return r
+
+    def one_step(measure):
         if net is None:
             eng.begin_move_uniform()
-            if timed:
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record()
-            eng.run_sims_uniform(S)
-            if timed:
-                b.record()
-                kern_ms.append((a, b))
+            timed(lambda: eng.run_sims_uniform(S), tree_ev, measure)
         else:
             if world > 1:                      # RCCL weight broadcast replaces model_server.latest()
                 dist.broadcast(flat, 0)
@@ -163,9 +187,10 @@ def main():
             eng.apply_root(p)
             bb, info = eng.select()
             for s in range(S):
-                p, v = evaluate(bb, info)
+                sample = measure and (s % 16 == 7)      # every 16th launch carries event pairs
+                p, v = timed(lambda: evaluate(bb, info), net_ev, sample)
                 if s < S - 1:
-                    bb, info = eng.sim_step(p, v)
+                    bb, info = timed(lambda: eng.sim_step(p, v), tree_ev, sample)
                 else:
                     eng.expand_backup(p, v)
         eng.choose_and_advance()
@@ -175,16 +200,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    for i in range(args.preroll):
+        one_step(False)
+        if i % 2 == 1:
+            eng.drain_finished()
     for _ in range(args.warmup):
         one_step(False)
     eng.drain_finished()
     st0 = eng.stats()
     sync_all()
     t0 = time.perf_counter()
-    ev_start.record()
     for i in range(args.steps):
         one_step(True)
-    ev_end.record()
     sync_all()
     elapsed = time.perf_counter() - t0
     st1 = eng.stats()
@@ -194,9 +221,8 @@ def main():
         elapsed = float(t.item())
 
     sims = st1['sims'] - st0['sims']
-    steps_sel = st1['select_steps'] - st0['select_steps']
     evals = st1['leaf_evals'] - st0['leaf_evals']
-    d = steps_sel / max(sims, 1)
+    d = (st1['select_steps'] - st0['select_steps']) / max(sims, 1)
     f = evals / max(sims, 1)
     assert sims == G * S * args.steps, (sims, G * S * args.steps)
     assert st1['errors'] == 0, 'node pool exhausted'
@@ -210,30 +236,46 @@ def main():
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * elapsed / args.steps,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f64 PUCT / f32 W,P / u32 N' + ('' if net is None else ' ; f32 net'),
+        'dtype': 'f64 PUCT score, f32 W/P, u32 N' + ('' if net is None else '; net trunk bf16 MFMA, f32 accumulate'),
         'data': 'synthetic',
-        'config': {'workload': f'connect4 self-play, {S} sims/move, {G} games/GPU, '
-                               f'exploration_depth 4, reuse_search_tree, model {args.model}',
-                   'games_per_gpu': G, 'sims_per_move': S, 'model': args.model,
-                   'net_impl': None if net is None else args.net_impl,
-                   'mean_select_depth': d, 'leaf_eval_fraction': f},
+        'config': {'workload': f'connect4 self-play, {S} sims/move, {G} games/GPU, exploration_depth 4, '
+                               f'reuse_search_tree, model {args.model}, {args.preroll} pre-roll moves',
+                   'games_per_gpu': G, 'sims_per_move': S, 'net': args.model,
+                   'net_impl': None if net is None else args.net_impl, 'preroll_moves': args.preroll,
+                   'mean_select_depth': d, 'leaf_eval_fraction': f,
+                   'games_finished': st1['games'] - st0['games']},
     }
     if rank == 0:
-        if kern_ms:
-            ms = sum(a.elapsed_time(b) for a, b in kern_ms) / len(kern_ms)
-            alg = bytes_per_sim(d, f) * G * S           # bytes one launch moves, algorithmically
-            gbs = alg / (ms * 1e-3) / 1e9
+        def avg_ms(pairs):
+            return sum(a.elapsed_time(b) for a, b in pairs) / len(pairs)
+        bps = bytes_per_sim(d, f)
+        if net is not None and args.net_impl == 'hip':
+            ms = avg_ms(net_ev)
+            fl = trunk_flops_per_leaf(6, 32) * f * G          # leaves one launch evaluates x flops per leaf
+            tf = fl / (ms * 1e-3) / 1e12
+            out['roofline'] = {'kernel': 'k_c4net_bf16', 'bound': 'mfma', 'achieved': tf, 'peak': BF16_PEAK_TFLOPS,
+                               'unit': 'TFLOP/s', 'frac': tf / BF16_PEAK_TFLOPS, 'traffic': None,
+                               'avg_launch_ms': ms, 'flops_per_leaf': trunk_flops_per_leaf(6, 32),
+                               'leaves_per_launch': f * G}
+            ms = avg_ms(tree_ev)
+            gbs = bps * G / (ms * 1e-3) / 1e9
+            out['roofline_tree'] = {'kernel': 'k_sim_step<GameC4,true,true>', 'bound': 'hbm', 'achieved': gbs,
+                                    'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+                                    'traffic': None, 'avg_launch_ms': ms, 'bytes_per_sim': bps}
+        elif net is None:
+            ms = avg_ms(tree_ev)
+            gbs = bps * G * S / (ms * 1e-3) / 1e9
             out['roofline'] = {'kernel': 'k_run_uniform<GameC4>', 'bound': 'hbm', 'achieved': gbs,
                                'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
-                               'traffic': None, 'avg_launch_ms': ms,
-                               'bytes_per_sim': bytes_per_sim(d, f)}
+                               'traffic': None, 'avg_launch_ms': ms, 'bytes_per_sim': bps}
         if not args.no_cpu_baseline:
             workers = min(16, os.cpu_count() or 1)
             pps, sps, npos, wall = cpu_baseline(args.model, S, args.cpu_seconds, workers)
             out['cpu_baseline'] = {'value': pps, 'unit': 'positions/s', 'sims_per_s': sps, 'cores': workers,
                                    'kind': 'port',
-                                   'sample': f'{npos} positions of whole oracle games in {wall:.1f} s, '
-                                             f'{workers} independent single-game workers, model {args.model}'}
+                                   'sample': f'{npos} self-play moves ({S} sims each) by the CPU oracle in {wall:.1f} s: '
+                                             f'{workers} independent single-game workers, one core and one net call '
+                                             f'per leaf each, model {args.model}'}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
