@@ -1,10 +1,12 @@
-// az_engine.hip -- wavefront-per-tree PUCT self-play engine for gfx950 (MI355X).
+// az_engine.hip -- PUCT self-play engine for gfx950 (MI355X): node pools, search kernels, C ABI.
 //
-// One 64-lane wavefront owns one game: its root position, its node pool and
-// its path stack.  Nothing is shared between games, so there are no atomics or
-// inter-workgroup hand-offs on the search path; parallelism is across games
-// only and each tree sees its simulations strictly in order, which is what
-// makes visit counts equal to the reference's (alphazero/mcts.py:110-158).
+// Every game owns its root position, its node pool and its path stack.  Nothing is shared
+// between games, so there are no atomics or inter-workgroup hand-offs on the search path;
+// parallelism is across games only and each tree sees its simulations strictly in order,
+// which is what makes visit counts equal to the reference's (alphazero/mcts.py:110-158).
+// The per-simulation kernels give each tree a group of 8 (Connect Four) or 16 (tic-tac-toe)
+// lanes, 8 or 4 trees per wavefront; the once-per-move kernels (root expansion + noise, move
+// choice) give each tree a whole wavefront.
 //
 // Node = (A+1) records of 16 B: edge i = {N u32, W f32, P f32, child u32},
 // last record = {num_edges, sum N, -, -}.  For Connect Four that is one
@@ -189,60 +191,8 @@ __device__ double gamma_draw(const Dev& E, uint64_t uid, uint32_t move, uint32_t
 }
 
 // ---------------------------------------------------------------------------
-// per-wave search primitives
+// per-tree primitives of the once-per-move kernels (one wavefront per tree)
 // ---------------------------------------------------------------------------
-struct Leaf {
-    int kind, depth, nm;
-    uint64_t nx, pv;
-    float v;
-};
-
-// mcts.py:119-134: descend from the root by first-argmax PUCT until a terminal
-// position or an edge without an expanded child.  Lane d keeps level d of the path.
-template <class GM>
-__device__ Leaf select_leaf(const Dev& E, const uint4* pool, uint32_t root, uint64_t nx, uint64_t pv,
-                            int nm, uint32_t& my_path, uint32_t& steps) {
-    constexpr int AS = GM::A + 1;
-    const int lane = lane_id();
-    Leaf L;
-    L.depth = 0; L.v = 0.0f; L.kind = AZ_LEAF_NONE;
-    uint32_t node = root;
-    if (GM::winner(nx, pv, nm) != AZ_W_NONE) {   // terminal root: the reference's loop body never runs
-        L.nx = nx; L.pv = pv; L.nm = nm;
-        return L;
-    }
-    for (;;) {
-        uint4 e = make_uint4(0u, 0u, 0u, AZ_NO_NODE);
-        if (lane < AS) e = pool[(size_t)node * AS + lane];
-        const int n_edges = (int)rdlane(e.x, AS - 1);
-        const uint32_t Ns = rdlane(e.y, AS - 1);
-        double cs, sq;
-        lut_lookup(E, Ns, cs, sq);
-        const bool act = lane < n_edges;
-        double score = -INFINITY;
-        if (act) score = puct_score(e.x, __uint_as_float(e.y), __uint_as_float(e.z), cs, sq);
-        const double mx = row16_max(score);
-        const unsigned long long hit = __ballot(act && score == mx);
-        const int slot = uni(__ffsll((long long)hit) - 1);            // np.argmax: first maximum
-        const uint32_t child = rdlane(e.w, slot);
-        const int action = az_nth_set_bit(GM::legal(nx, pv), slot);    // mcts.py:126
-        if (lane == L.depth) my_path = (node << 4) | (uint32_t)slot;
-        L.depth += 1;
-        steps += 1;
-        GM::play(nx, pv, nm, action);
-        const int w = GM::winner(nx, pv, nm);
-        if (w != AZ_W_NONE) {                                          // mcts.py:131-134
-            L.kind = AZ_LEAF_TERMINAL;
-            L.v = az_terminal_value_prev(w, nm);
-            break;
-        }
-        if (child == AZ_NO_NODE) { L.kind = AZ_LEAF_EVAL; break; }    // mcts.py:135-138
-        node = child;
-    }
-    L.nx = nx; L.pv = pv; L.nm = nm;
-    return L;
-}
-
 // mcts.py:20-26: one new node; priors compacted to the legal moves in ascending
 // action order.  p == nullptr gives the UniformModel prior 1/n (models.py:90-95).
 template <class GM>
@@ -266,24 +216,6 @@ __device__ uint32_t expand_node(const Dev& E, uint4* pool, uint32_t& alloc, uint
         pool[(size_t)idx * AS + lane] = rec;
     }
     return idx;
-}
-
-// mcts.py:147-158: every level of the path in parallel (levels are distinct nodes)
-template <class GM>
-__device__ void backup_path(uint4* pool, int depth, uint32_t my_path, float v_leaf_edge) {
-    constexpr int AS = GM::A + 1;
-    const int lane = lane_id();
-    if (lane < depth) {
-        const uint32_t node = my_path >> 4, slot = my_path & 15u;
-        const float v = ((depth - 1 - lane) & 1) ? -v_leaf_edge : v_leaf_edge;
-        uint2* ep = reinterpret_cast<uint2*>(&pool[(size_t)node * AS + slot]);
-        uint2 nw = *ep;
-        nw.x += 1u;                                                   // mcts.py:86
-        nw.y = __float_as_uint(__uint_as_float(nw.y) + v);            // mcts.py:85 (fp32)
-        *ep = nw;
-        uint32_t* ns = reinterpret_cast<uint32_t*>(&pool[(size_t)node * AS + AS - 1]) + 1;
-        *ns += 1u;
-    }
 }
 
 // mcts.py:88-91
@@ -379,87 +311,6 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_apply_root(Dev E, const float
         s->root = root; s->alloc = alloc; s->err = err; s->move_sims = 0;
         s->leaf_kind = AZ_LEAF_NONE;
         if (need) s->st_root_evals += 1;
-    }
-}
-
-// mcts.py:119-158, one simulation per game per launch:
-//   DO_EXPAND: finish the pending simulation with the evaluator's (p, v);
-//   DO_SELECT: start the next one; terminal leaves are backed up at once.
-template <class GM, bool DO_EXPAND, bool DO_SELECT>
-__global__ void __launch_bounds__(BLOCK_THREADS)
-k_sim_step(Dev E, const float* p, const float* v, uint64_t* leaf_bb, int32_t* leaf_info) {
-    WAVE_PROLOGUE
-    uint32_t alloc = s->alloc, err = s->err;
-    const uint32_t root = s->root;
-    uint32_t sims = 0, evals = 0, steps = 0;
-    int kind = s->leaf_kind;
-
-    if (DO_EXPAND && kind == AZ_LEAF_EVAL) {
-        const int depth = s->leaf_depth;
-        const uint32_t my_path = lane < depth ? s->path[lane] : 0u;
-        const uint32_t idx = expand_node<GM>(E, pool, alloc, s->leaf_nx, s->leaf_pv, p + (size_t)g * GM::A, err);
-        const uint32_t last = rdlane(my_path, depth - 1);
-        if (idx != AZ_NO_NODE && lane == 0)
-            reinterpret_cast<uint32_t*>(&pool[(size_t)(last >> 4) * (GM::A + 1) + (last & 15u)])[3] = idx;
-        backup_path<GM>(pool, depth, my_path, -v[g]);                  // mcts.py:144
-        sims += 1; evals += 1;
-        kind = AZ_LEAF_NONE;
-        if (DO_SELECT) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    }
-
-    if (DO_SELECT) {
-        Leaf L;
-        L.kind = AZ_LEAF_NONE; L.depth = 0; L.nx = s->nx; L.pv = s->pv; L.nm = s->nm; L.v = 0.f;
-        uint32_t my_path = 0;
-        if (root != AZ_NO_NODE) L = select_leaf<GM>(E, pool, root, s->nx, s->pv, s->nm, my_path, steps);
-        if (L.kind == AZ_LEAF_TERMINAL) {
-            backup_path<GM>(pool, L.depth, my_path, L.v);
-            sims += 1;
-        } else if (L.kind == AZ_LEAF_EVAL) {
-            if (lane < L.depth) s->path[lane] = my_path;
-        }
-        kind = L.kind;
-        if (lane == 0) {
-            s->leaf_depth = L.depth; s->leaf_nx = L.nx; s->leaf_pv = L.pv; s->leaf_nm = L.nm;
-            leaf_bb[2 * (size_t)g] = L.nx; leaf_bb[2 * (size_t)g + 1] = L.pv;
-            leaf_info[g] = L.kind | (L.nm << 8) | ((int)GM::legal(L.nx, L.pv) << 16);
-        }
-    }
-    if (lane == 0) {
-        s->leaf_kind = kind; s->alloc = alloc; s->err = err;
-        s->move_sims += sims; s->st_sims += sims; s->st_evals += evals; s->st_steps += steps;
-    }
-}
-
-// num_sims whole simulations per game in one launch, UniformModel evaluated in place
-template <class GM>
-__global__ void __launch_bounds__(BLOCK_THREADS) k_run_uniform(Dev E, int num_sims) {
-    WAVE_PROLOGUE
-    uint32_t alloc = s->alloc, err = s->err;
-    const uint32_t root = s->root;
-    const uint64_t nx = s->nx, pv = s->pv;
-    const int nm = s->nm;
-    uint32_t sims = 0, evals = 0, steps = 0;
-    if (root == AZ_NO_NODE) return;
-    for (int it = 0; it < num_sims; ++it) {
-        uint32_t my_path = 0;
-        const Leaf L = select_leaf<GM>(E, pool, root, nx, pv, nm, my_path, steps);
-        if (L.kind == AZ_LEAF_EVAL) {
-            const uint32_t idx = expand_node<GM>(E, pool, alloc, L.nx, L.pv, nullptr, err);
-            const uint32_t last = rdlane(my_path, L.depth - 1);
-            if (idx != AZ_NO_NODE && lane == 0)
-                reinterpret_cast<uint32_t*>(&pool[(size_t)(last >> 4) * (GM::A + 1) + (last & 15u)])[3] = idx;
-            backup_path<GM>(pool, L.depth, my_path, -0.0f);            // v = 0, then v *= -1
-            evals += 1;
-        } else if (L.kind == AZ_LEAF_TERMINAL) {
-            backup_path<GM>(pool, L.depth, my_path, L.v);
-        }
-        sims += 1;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // own stores before next select's loads
-    }
-    if (lane == 0) {
-        s->alloc = alloc; s->err = err; s->leaf_kind = AZ_LEAF_NONE;
-        s->move_sims += sims; s->st_sims += sims; s->st_evals += evals; s->st_steps += steps;
     }
 }
 

@@ -1,0 +1,85 @@
+"""The two exchange steps of multi-GPU self-play, over torch.distributed (RCCL on GPUs,
+gloo in CPU tests).  Games shard across ranks with no data-path collective; these replace
+the reference's Redis model server and SQLite sink between processes:
+
+  broadcast_model  <-  ModelServer.update / latest   (alphazero/model_server.py:19-40)
+  gather_records   <-  ReplayBufferDataset.add_game   (alphazero/replay_buffer.py:165-167)
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from ._lib import GameRecord
+
+RECORD_BYTES = C.sizeof(GameRecord)
+
+
+def shard_uids(rank, world_size, games_per_rank):
+    """(first_game_uid, uid_stride) for az_engine_config: rank r owns uids r*G+g + k*world*G."""
+    return rank * games_per_rank, world_size * games_per_rank
+
+
+def _unique_state_tensors(model):
+    """state_dict tensors with aliases removed (the reference's tower repeats one block)."""
+    seen, out = set(), []
+    for t in model.state_dict().values():
+        if t.data_ptr() not in seen:
+            seen.add(t.data_ptr())
+            out.append(t)
+    return out
+
+
+def broadcast_model(model, version, src=0, group=None):
+    """One broadcast of [version | all weights and BN statistics] from `src`; every rank returns
+    the version and has the weights loaded in place.  ~137 KB for the 6x32 net: latency-bound."""
+    tensors = _unique_state_tensors(model)
+    dev = tensors[0].device
+    flat = torch.cat([torch.tensor([float(version)], dtype=torch.float64, device=dev).view(torch.uint8)] +
+                     [t.detach().contiguous().view(-1).view(torch.uint8) for t in tensors])
+    dist.broadcast(flat, src, group=group)
+    version = int(flat[:8].view(torch.float64).item())
+    off = 8
+    with torch.no_grad():
+        for t in tensors:
+            n = t.numel() * t.element_size()
+            t.copy_(flat[off:off + n].view(t.dtype).view(t.shape))
+            off += n
+    return version
+
+
+def records_to_bytes(records):
+    """list of az_game_record (ctypes) -> uint8 array [n, RECORD_BYTES]."""
+    out = np.zeros((len(records), RECORD_BYTES), np.uint8)
+    for i, r in enumerate(records):
+        out[i] = np.frombuffer(bytes(r), np.uint8)
+    return out
+
+
+def bytes_to_records(arr):
+    arr = np.ascontiguousarray(arr, np.uint8).reshape(-1, RECORD_BYTES)
+    return [GameRecord.from_buffer_copy(arr[i].tobytes()) for i in range(arr.shape[0])]
+
+
+def gather_records(records, dst=0, device=None, group=None):
+    """Finished games of every rank collected on `dst` (list of az_game_record there, [] elsewhere).
+    Fixed-size records, one count exchange + one padded all_gather: a few MB per generation."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    device = device or ('cuda' if dist.get_backend(group) == 'nccl' else 'cpu')
+    mine = torch.from_numpy(records_to_bytes(records)).to(device)
+    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([mine.shape[0]], dtype=torch.int64, device=device), group=group)
+    counts = [int(c.item()) for c in counts]
+    cap = max(max(counts), 1)
+    padded = torch.zeros(cap, RECORD_BYTES, dtype=torch.uint8, device=device)
+    padded[:mine.shape[0]] = mine
+    bufs = [torch.zeros_like(padded) for _ in range(world)]
+    dist.all_gather(bufs, padded, group=group)
+    if rank != dst:
+        return []
+    out = []
+    for r in range(world):
+        out.extend(bytes_to_records(bufs[r][:counts[r]].cpu().numpy()))
+    return out

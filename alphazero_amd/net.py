@@ -25,103 +25,91 @@ def _fold_bn(w, bn, conv_bias=None):
     return w.double() * s.view(-1, 1, 1, 1), shift
 
 
-def _bf16_bits(t):
-    return t.float().to(torch.bfloat16).view(torch.int16).numpy()
+_FRAG_INDEX = {}
 
 
-def _lane_k(s):
-    """(row, k) held by element j of lane l in k-step s of a 32x32x16 MFMA A fragment:
-    row = l & 31, k = 16*s + 8*(l >> 5) + j.  Returns index tensors [64, 8]."""
-    lane = torch.arange(64).view(64, 1)
-    j = torch.arange(8).view(1, 8)
-    return (lane & 31).expand(64, 8), (16 * s + 8 * (lane >> 5) + j).expand(64, 8)
+def _frag_index(ksteps, device):
+    """Flat gather index of MFMA A fragments [ksteps][64][8] into a row-major [32][16*ksteps]
+    matrix: element j of lane l in k-step s is Wt[row = l & 31][k = 16*s + 8*(l >> 5) + j]."""
+    key = (ksteps, str(device))
+    if key not in _FRAG_INDEX:
+        s = torch.arange(ksteps).view(-1, 1, 1)
+        lane = torch.arange(64).view(1, -1, 1)
+        j = torch.arange(8).view(1, 1, -1)
+        idx = (lane & 31) * (16 * ksteps) + 16 * s + 8 * (lane >> 5) + j
+        _FRAG_INDEX[key] = idx.reshape(-1).to(device)
+    return _FRAG_INDEX[key]
 
 
 def _gemm_frags(mat, ksteps):
-    """Dense matrix [rows <= 32][K] -> fragments [ksteps][64][8] of Wt[row][k], zero padded."""
+    """Dense matrix [rows <= 32][K <= 16*ksteps] -> bf16 fragment bytes (uint8 tensor)."""
     rows, K = mat.shape
-    pad = torch.zeros(32, 16 * ksteps, dtype=torch.float64)
+    pad = torch.zeros(32, 16 * ksteps, dtype=torch.float64, device=mat.device)
     pad[:rows, :K] = mat
-    out = torch.zeros(ksteps, 64, 8, dtype=torch.float64)
-    for s in range(ksteps):
-        r, k = _lane_k(s)
-        out[s] = pad[r, k]
-    return _bf16_bits(out)
+    fr = pad.reshape(-1)[_frag_index(ksteps, mat.device)]
+    return fr.float().to(torch.bfloat16).contiguous().view(torch.uint8)
 
 
-def _conv_frags(w):
-    """Folded 3x3 conv weight [co <= 32][ci <= 32][3][3] -> [18][64][8]; k-step s covers tap s >> 1 and
-    input channels 16*(s & 1) .. +15, i.e. k = tap*32 + ci."""
+def _conv_matrix(w):
+    """Folded 3x3 conv weight [co][ci][3][3] -> [co][9*32] with k = tap*32 + ci."""
     co, ci = w.shape[:2]
-    mat = torch.zeros(32, 9 * 32, dtype=torch.float64)
-    for tap in range(9):
-        mat[:co, tap * 32:tap * 32 + ci] = w[:, :, tap // 3, tap % 3]
-    return _gemm_frags(mat, 18)
+    mat = torch.zeros(co, 9, 32, dtype=torch.float64, device=w.device)
+    mat[:, :, :ci] = w.permute(0, 2, 3, 1).reshape(co, 9, ci)
+    return mat.reshape(co, 288)
+
+
+def _f32_bytes(t, pad_to=None):
+    t = t.detach().reshape(-1).float()
+    if pad_to and t.numel() < pad_to:
+        t = torch.cat([t, torch.zeros(pad_to - t.numel(), device=t.device)])
+    return t.contiguous().view(torch.uint8)
 
 
 def pack_c4_blob(model):
-    """AlphaZeroC4 module -> uint8 blob in the layout of csrc/az_net.hip."""
+    """AlphaZeroC4 module -> uint8 tensor (on the module's device) in the layout of
+    csrc/az_net.hip.  A handful of tensor ops, so it can run after every weight broadcast."""
     C_ = model.block_channels
     if C_ > CMAX:
         raise ValueError(f'fused kernel supports up to {CMAX} trunk channels, got {C_}')
     if tuple(model.shape_in) != (2, 6, 7):
         raise ValueError('fused kernel is for Connect Four (2x6x7 input)')
-    lib = _lib.load()
-    blob = np.zeros(lib.az_c4net_blob_bytes(), np.uint8)
-    off = 0
-
-    def put(arr):
-        nonlocal off
-        a = np.ascontiguousarray(arr).reshape(-1).view(np.uint8)
-        blob[off:off + a.size] = a
-        off += a.size
-
-    def putf(arr, pad_to=None):
-        a = np.ascontiguousarray(arr, np.float32).reshape(-1)
-        if pad_to:
-            a = np.concatenate([a, np.zeros(pad_to - a.size, np.float32)])
-        put(a)
-
+    dev = model._cbr[0].weight.device
+    parts = []
     with torch.no_grad():
-        bias = np.zeros((3, 32), np.float32)
+        bias = torch.zeros(3, 32, dtype=torch.float64, device=dev)
         # stem: K index = tap*2 + plane
-        w, b = _fold_bn(model._cbr[0].weight.cpu(), model._cbr[1].cpu())
-        mat = torch.zeros(C_, 18, dtype=torch.float64)
-        for tap in range(9):
-            mat[:, 2 * tap] = w[:, 0, tap // 3, tap % 3]
-            mat[:, 2 * tap + 1] = w[:, 1, tap // 3, tap % 3]
-        put(_gemm_frags(mat, 2))
-        bias[0, :C_] = b.float().numpy()
+        w, b = _fold_bn(model._cbr[0].weight, model._cbr[1])
+        parts.append(_gemm_frags(w.permute(0, 2, 3, 1).reshape(C_, 18), 2))
+        bias[0, :C_] = b
         if len(model._tower):
             blk = model._tower[0]
             for i, (cv, bn) in enumerate(((blk._c1, blk._bn1), (blk._c2, blk._bn2))):
-                w, b = _fold_bn(cv.weight.cpu(), bn.cpu())
-                put(_conv_frags(w))
-                bias[1 + i, :C_] = b.float().numpy()
+                w, b = _fold_bn(cv.weight, bn)
+                parts.append(_gemm_frags(_conv_matrix(w), 18))
+                bias[1 + i, :C_] = b
         else:
-            off += 2 * 18 * 1024
+            parts.append(torch.zeros(2 * 18 * 1024, dtype=torch.uint8, device=dev))
         # heads: 1x1 convs -> rows 0,1 (policy planes) and 2 (value plane) of one [32][32] matrix
         ph, vh = model._policy_head, model._value_head
-        wpol, bpol = _fold_bn(ph._cbr[0].weight.cpu(), ph._cbr[1].cpu(), ph._cbr[0].bias.cpu())
-        wval, bval = _fold_bn(vh._cbr[0].weight.cpu(), vh._cbr[1].cpu())
-        mat = torch.zeros(3, 32, dtype=torch.float64)
+        wpol, bpol = _fold_bn(ph._cbr[0].weight, ph._cbr[1], ph._cbr[0].bias)
+        wval, bval = _fold_bn(vh._cbr[0].weight, vh._cbr[1])
+        mat = torch.zeros(3, 32, dtype=torch.float64, device=dev)
         mat[0:2, :C_] = wpol[:, :, 0, 0]
         mat[2, :C_] = wval[0, :, 0, 0]
-        put(_gemm_frags(mat, 2))
-        # value FC1 [256][42]: 8 row tiles x 3 k-steps
-        w1 = vh._fc[0].weight.cpu().double()
+        parts.append(_gemm_frags(mat, 2))
+        w1 = vh._fc[0].weight.double()                          # value FC1 [256][42]: 8 row tiles x 3 k-steps
         for t in range(8):
-            put(_gemm_frags(w1[32 * t:32 * t + 32], 3))
-        # policy FC [42][84]: 2 row tiles x 6 k-steps
-        wp = ph._fc.weight.cpu().double()
-        put(_gemm_frags(wp[0:32], 6))
-        put(_gemm_frags(wp[32:42], 6))
-        putf(np.concatenate([bias.reshape(-1), [float(bpol[0]), float(bpol[1]), float(bval[0]), 0.0]]))
-        putf(ph._fc.bias.cpu().numpy(), 64)
-        putf(vh._fc[0].bias.cpu().numpy())
-        putf(vh._fc[2].weight.cpu().numpy())
-        putf(np.array([vh._fc[2].bias.item(), 0, 0, 0]))
-    assert off == blob.size, (off, blob.size)
+            parts.append(_gemm_frags(w1[32 * t:32 * t + 32], 3))
+        wp = ph._fc.weight.double()                             # policy FC [42][84]: 2 row tiles x 6 k-steps
+        parts.append(_gemm_frags(wp[0:32], 6))
+        parts.append(_gemm_frags(wp[32:42], 6))
+        parts.append(_f32_bytes(torch.cat([bias.reshape(-1), bpol[:2], bval[:1], torch.zeros(1, dtype=torch.float64, device=dev)])))
+        parts.append(_f32_bytes(ph._fc.bias, 64))
+        parts.append(_f32_bytes(vh._fc[0].bias))
+        parts.append(_f32_bytes(vh._fc[2].weight))
+        parts.append(_f32_bytes(torch.cat([vh._fc[2].bias.reshape(1), torch.zeros(3, device=dev)])))
+        blob = torch.cat(parts)
+    assert blob.numel() == _lib.load().az_c4net_blob_bytes(), (blob.numel(), _lib.load().az_c4net_blob_bytes())
     return blob
 
 
@@ -130,7 +118,7 @@ class FusedC4Net:
         self.lib = _lib.load()
         self.device = torch.device(device)
         self.num_blocks = int(num_blocks)
-        self.blob = torch.from_numpy(blob).to(self.device)
+        self.blob = blob.to(self.device).contiguous()
         self._p = self._v = None
 
     @classmethod
@@ -140,7 +128,7 @@ class FusedC4Net:
 
     def load_module(self, model):
         """Refresh the packed weights from `model` (after a weight broadcast / optimiser step)."""
-        self.blob.copy_(torch.from_numpy(pack_c4_blob(model)))
+        self.blob.copy_(pack_c4_blob(model))
         self.num_blocks = model.num_blocks
 
     def __call__(self, leaf_bb, leaf_info):

@@ -44,7 +44,14 @@ class SelfPlayWorker:
             exploration_depth=sp['exploration_depth'], reuse_search_tree=sp['reuse_search_tree'],
             seed=seed, device=dev_index, first_game_uid=rank * self.num_games,
             uid_stride=world_size * self.num_games)
-        self._evaluator = evaluator           # callable(leaf_bb, leaf_info) -> (p, v); None = torch model
+        self._evaluator = evaluator           # callable(leaf_bb, leaf_info) -> (p, v); None = built-in
+        self._fused = None
+        if evaluator is None:
+            # Connect Four nets with <= 32 trunk channels run in the fused HIP kernel
+            from .models import AlphaZeroC4
+            from .net import CMAX, FusedC4Net
+            if isinstance(self._model, AlphaZeroC4) and self._model.block_channels <= CMAX:
+                self._fused = FusedC4Net.from_module(self._model, self._device)
         self._version = 0
         self.positions = 0
         self.games_finished = 0
@@ -53,6 +60,8 @@ class SelfPlayWorker:
     def _eval(self, bb, info):
         if self._evaluator is not None:
             return self._evaluator(bb, info)
+        if self._fused is not None:
+            return self._fused(bb, info)
         return evaluate_leaves(self.engine.game, self._model, bb, info)
 
     def play_move(self, uniform):
@@ -86,6 +95,8 @@ class SelfPlayWorker:
         """selfplay.py:16-22: pull the latest weights; version 0 means 'no model yet'."""
         self._version = int(self._model_server.latest(self._model))
         self.engine.set_model_version(self._version)
+        if self._fused is not None and self._version > 0:
+            self._fused.load_module(self._model)
         return self._version
 
     def play_game(self):
@@ -103,8 +114,6 @@ class SelfPlayWorker:
         uniform = version <= 0 and self._evaluator is None
         for _ in range(num_moves):
             self.play_move(uniform)
-            # the ring holds 2*G records; a slot finishes at most one game per move
-            if (_ + 1) % 2 == 0:
-                self.collect_finished()
+            self.collect_finished()       # the ring holds 2*G records; one small D2H per move
         self.collect_finished()
         return version

@@ -1,0 +1,57 @@
+"""TrainingWorker with the reference's constructor and process_batch() contract
+(alphazero/training.py:15-125): SGD + momentum + weight decay, MultiStepLR, masked
+cross-entropy + MSE, weights published after every step.  Host-side torch code; the summary
+writer and model server are duck-typed (`add_scalar`, `update(model, version)`)."""
+import torch
+from torch.optim import SGD
+from torch.optim.lr_scheduler import MultiStepLR
+
+from .replay_buffer import ReplayBufferSampler
+
+
+class TrainingWorker:
+    def __init__(self, config, model_server, dataset, summary_writer, device, num_workers=0):
+        self._config, self._model_server, self._dataset = config, model_server, dataset
+        self._writer, self._device, self._num_workers = summary_writer, device, num_workers
+        self._model = config.Model().to(device)
+        self._loss = config.Loss()
+        t = config.training
+        self._optimizer = SGD(self._model.parameters(), lr=t['lr'], momentum=t['momentum'],
+                              weight_decay=t['weight_decay'])
+        self._lr_schedule = MultiStepLR(self._optimizer, t['lr_schedule'], gamma=t['lr_schedule_gamma'])
+        self._sampler = ReplayBufferSampler(dataset, batch_size=t['batch_size'], bufferlen=64 * 1024)
+        self._iter = 0
+
+    @property
+    def model(self):
+        return self._model
+
+    def _batch(self):
+        items = [self._dataset[i] for i in next(self._sampler)]
+        stack = lambda k, dt: torch.as_tensor(__import__('numpy').stack([it[k] for it in items])).to(self._device, dt)
+        return stack('x', torch.float32), stack('p', torch.float32), stack('z', torch.float32), stack('p_valid', torch.bool)
+
+    def process_batch(self):
+        N, B = len(self._dataset), self._config.training['batch_size']
+        M = max(2 * self._num_workers, 1) * B
+        if N < M:
+            print(f'Skipping batch, too few examples in replay buffer ({N} < {M}).')
+            return 0
+        self._model.train()
+        x, p, z, p_valid = self._batch()
+        p_hat, v_hat = self._model(x, p_valid)
+        policy_loss, value_loss = self._loss(p, z, p_hat, v_hat, p_valid)
+        self._optimizer.zero_grad()
+        total = policy_loss + value_loss
+        total.backward()
+        self._optimizer.step()
+        self._lr_schedule.step()
+        it = self._iter
+        self._iter += 1
+        self._model_server.update(self._model, it + 1)
+        if self._writer is not None:
+            self._writer.add_scalar('loss/policy', policy_loss, it)
+            self._writer.add_scalar('loss/value', value_loss, it)
+            self._writer.add_scalar('loss/total', total, it)
+            self._writer.add_scalar('optim/learning_rate', self._lr_schedule.get_last_lr()[0], it)
+        return it + 1

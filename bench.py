@@ -155,7 +155,7 @@ def main():
         blocks, ch = 6, 32                      # alphazero/config/connectfour.yaml:4-9
         torch.manual_seed(0)
         net = AlphaZeroC4(blocks, ch).to(dev).eval()
-        flat = torch.nn.utils.parameters_to_vector(net.parameters()).detach()
+        from alphazero_amd.distributed import broadcast_model
         if args.net_impl == 'hip':
             from alphazero_amd.net import FusedC4Net
             fused = FusedC4Net.from_module(net, dev)
@@ -180,8 +180,12 @@ def main():
             eng.begin_move_uniform()
             timed(lambda: eng.run_sims_uniform(S), tree_ev, measure)
         else:
-            if world > 1:                      # RCCL weight broadcast replaces model_server.latest()
-                dist.broadcast(flat, 0)
+            if world > 1:
+                # RCCL weight broadcast replaces model_server.latest() (model_server.py:32-40);
+                # the fused kernel's packed weights are rebuilt from the received tensors
+                broadcast_model(net, 1, src=0)
+                if args.net_impl == 'hip':
+                    fused.load_module(net)
             bb, info = eng.begin_move()
             p, _ = evaluate(bb, info)
             eng.apply_root(p)

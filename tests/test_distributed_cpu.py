@@ -1,0 +1,86 @@
+"""N > 1 path on CPU: two gloo ranks exercise game-uid sharding, the weight broadcast and the
+finished-game gather (the same code runs over RCCL on GPUs)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _fake_records(rank, n):
+    from alphazero_amd._lib import GameRecord
+    recs = []
+    for i in range(n):
+        r = GameRecord()
+        r.uid = rank * 1000 + i
+        r.num_moves = 7 + i
+        r.winner = i % 2
+        r.model_version = 5
+        for m in range(r.num_moves):
+            r.history[m] = (m + rank) % 7
+            r.num_edges[m] = 7
+            for a in range(7):
+                r.visits[m][a] = 100 * rank + 10 * m + a
+        recs.append(r)
+    return recs
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from alphazero_amd import distributed as D
+    from alphazero_amd.models import AlphaZeroC4
+    # --- sharding: disjoint uid sets
+    first, stride = D.shard_uids(rank, world, 8)
+    uids = {first + g + k * stride for g in range(8) for k in range(3)}
+    gathered = [None] * world
+    dist.all_gather_object(gathered, uids)
+    assert sum(len(u) for u in gathered) == len(set().union(*gathered))
+    # --- weight broadcast: rank 0's weights and version arrive everywhere, aliases intact
+    torch.manual_seed(rank)
+    model = AlphaZeroC4(2, 8)
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.fill_(0.1 * (rank + 1))
+    ref = AlphaZeroC4(2, 8)
+    torch.manual_seed(0)
+    ref0 = AlphaZeroC4(2, 8)
+    version = D.broadcast_model(model, 17 if rank == 0 else -1, src=0)
+    assert version == 17
+    for k, v in model.state_dict().items():
+        if 'running_mean' in k:
+            assert torch.all(v == 0.1), k
+        elif 'num_batches_tracked' not in k and 'running_var' not in k:
+            assert torch.equal(v, ref0.state_dict()[k]), k
+    sd = model.state_dict()
+    assert sd['_tower.0._c1.weight'].data_ptr() == sd['_tower.1._c1.weight'].data_ptr()
+    # --- record gather: uneven counts, including an empty rank
+    recs = _fake_records(rank, 0 if rank == 1 else 3)
+    got = D.gather_records(recs, dst=0)
+    if rank == 0:
+        assert len(got) == 3
+        assert sorted(r.uid for r in got) == [0, 1, 2]
+        assert got[1].visits[2][3] == 23 and got[2].num_moves == 9
+    else:
+        assert got == []
+    recs = _fake_records(rank, 2 + rank)
+    got = D.gather_records(recs, dst=0)
+    if rank == 0:
+        assert sorted(r.uid for r in got) == [0, 1, 1000, 1001, 1002]
+        r = [x for x in got if x.uid == 1002][0]
+        assert r.history[3] == 4 and r.visits[5][6] == 156 and r.model_version == 5
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(out_dir, f'ok{rank}'), 'w').write('ok')
+
+
+def test_two_rank_gloo_sharding_broadcast_gather(tmp_path):
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / 'ok0') and os.path.exists(tmp_path / 'ok1')

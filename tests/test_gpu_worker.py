@@ -1,0 +1,85 @@
+"""SelfPlayWorker (the reference's play_game() contract) end to end on the GPU."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+class _Server:
+    def __init__(self, version, state=None):
+        self.version, self.state, self.calls = version, state, 0
+
+    def latest(self, model):
+        self.calls += 1
+        if self.state is not None:
+            model.load_state_dict(self.state)
+        return self.version
+
+
+class _Dataset:
+    def __init__(self):
+        self.games = []
+
+    def add_game(self, game, version):
+        assert game.terminal
+        self.games.append((game, version))
+
+
+def _config(game, model, S, depth=4, reuse=True):
+    from alphazero_amd.config import AlphaZeroConfig
+    return AlphaZeroConfig(conf={'game': game, 'model': model,
+                                 'selfplay': {'num_expansions_per_sim': S, 'exploration_depth': depth,
+                                              'reuse_search_tree': reuse}})
+
+
+def _check_games(ds, game_id, S, reuse):
+    assert ds.games
+    for game, version in ds.games:
+        h = game.history
+        assert orc.terminal(game_id, h) and not orc.terminal(game_id, h[:-1])
+        assert len(game.search_statistics) == len(h)
+        for i, n in enumerate(game.search_statistics):
+            assert n.dtype == np.uint32 and len(n) == len(orc.valid_actions(game_id, h[:i]))
+            if reuse:
+                assert int(n.sum()) >= S            # carried-over visits are included (selfplay.py:31)
+            else:
+                assert int(n.sum()) == S
+            assert h[i] in orc.valid_actions(game_id, h[:i])
+
+
+def test_uniform_model_version_zero_ttt():
+    # alphazero/test/configs/tictactoe.yaml: UniformModel, version 0 -> in-kernel uniform evaluation
+    from alphazero_amd.selfplay import SelfPlayWorker
+    cfg = _config({'module': 'alphazero.games.tictactoe', 'name': 'TicTacToe'},
+                  {'module': 'alphazero.models', 'name': 'UniformModel'}, S=32, depth=3, reuse=False)
+    ds, srv = _Dataset(), _Server(0)
+    w = SelfPlayWorker(cfg, srv, ds, 'cuda', num_games=64, seed=1)
+    assert w.play_game() == 0 and srv.calls == 1
+    _check_games(ds, orc.TTT, 32, False)
+    assert all(v == 0 for _, v in ds.games)
+    assert w.engine.stats()['errors'] == 0
+
+
+def test_c4_net_fused_and_torch_paths():
+    from alphazero_amd.models import AlphaZeroC4
+    from alphazero_amd.selfplay import SelfPlayWorker
+    model = {'module': 'alphazero.games.connectfour', 'name': 'AlphaZeroC4',
+             'kwargs': {'num_blocks': 2, 'channels_per_block': 16}}
+    cfg = _config({'module': 'alphazero.games.connectfour', 'name': 'ConnectFour'}, model, S=24)
+    torch.manual_seed(0)
+    state = AlphaZeroC4(2, 16).state_dict()
+    for use_torch in (False, True):
+        ds, srv = _Dataset(), _Server(7, state)
+        w = SelfPlayWorker(cfg, srv, ds, 'cuda', num_games=48, seed=2)
+        assert (w._fused is not None)
+        if use_torch:
+            w._fused = None                          # module path: az_render + torch + az_masked_softmax
+        while len(ds.games) < 48:
+            assert w.play_game() == 7
+        _check_games(ds, orc.C4, 24, True)
+        assert all(v == 7 for _, v in ds.games)
+        assert len({tuple(g.history) for g, _ in ds.games}) > 10     # device RNG: games differ
+        assert w.engine.stats()['errors'] == 0
