@@ -45,14 +45,18 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define TILES_PER_WAVE 3          // TB*48/32 = 24 tiles of 32 positions over 8 waves
 
 // LDS scratch after the two activation images
-#define S_BIAS 0                              // float[3][32] + head bias [4]  (400 B -> 512)
-#define S_HP 512                              // bf16 [TB][96] policy planes, k = ch*42 + cell
-#define S_HV (S_HP + TB * 96 * 2)             // bf16 [TB][48] value plane
-#define S_LG (S_HV + TB * 48 * 2)             // float [TB][64] cell logits
-#define S_VP (S_LG + TB * 64 * 4)             // float [8][32] value partial sums per wave
-#define S_TL (S_VP + 8 * 32 * 4)                // int [MAX_LIST] game index of each board this WG evaluates
-#define MAX_LIST 256
-#define S_WT (S_TL + MAX_LIST * 4)            // int [16] scan scratch
+#define S_BIAS 0                              // float[3][32] conv biases + head bias [4]
+#define S_B1 512                              // float[256] value FC1 bias
+#define S_W2 (S_B1 + 1024)                    // float[256] value FC2 weights
+#define S_BP (S_W2 + 1024)                    // float[64]  policy FC bias
+#define S_PW (S_BP + 256)                     // per-wave head scratch, PW_BYTES each:
+#define PW_HP 0                               //   bf16 [2][96] policy planes, k = ch*42 + cell
+#define PW_HV 384                             //   bf16 [2][48] value plane
+#define PW_LG 576                             //   float [2][64] cell logits
+#define PW_BYTES 1152
+#define MAXIT 8                               // wave-tasks per wave per launch (n <= 32768)
+#define S_TL (S_PW + 8 * PW_BYTES)            // int [8 waves][MAXIT][2] leaf index of each board
+#define S_WT (S_TL + 8 * MAXIT * 2 * 4)       // int [16] scan scratch
 #define S_BYTES (S_WT + 64)
 #define LDS_BYTES (2 * ACT_BYTES + S_BYTES)
 
@@ -169,7 +173,7 @@ __device__ __forceinline__ void stem(const uint8_t* blob, const uint64_t* leaf_b
         const int b = R / 48, o = R - b * 48;
         const int pos = b * BOARD_POS + POS0 + o;
         const int y = o >> 3, x = o & 7;
-        const int gidx = games[b];
+        const int gidx = games[b - 2 * wave];
         uint64_t bb[2] = {0, 0};
         if (gidx >= 0) { bb[0] = leaf_bb[2 * (size_t)gidx] << 8; bb[1] = leaf_bb[2 * (size_t)gidx + 1] << 8; }
         // after the shift, cell (xx, yy) with xx in -1..7, yy in -1..6 is bit (xx+1)*7 + yy + 1;
@@ -203,19 +207,16 @@ __device__ __forceinline__ void stem(const uint8_t* blob, const uint64_t* leaf_b
 
 __global__ void __launch_bounds__(NTHREADS, 2)
 k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* __restrict__ leaf_bb,
-             const int32_t* __restrict__ leaf_info, int n, float* __restrict__ p_out, float* __restrict__ v_out) {
+             const int32_t* __restrict__ leaf_info, int n, float* __restrict__ p_out, float* __restrict__ v_out,
+             int grid_shift) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t* bufX = lds;                       // conv1 output
     uint8_t* bufY = lds + ACT_BYTES;           // block input and output
     uint8_t* scr = lds + 2 * ACT_BYTES;
     float* sbias = reinterpret_cast<float*>(scr + S_BIAS);
-    __bf16* hp = reinterpret_cast<__bf16*>(scr + S_HP);
-    __bf16* hv = reinterpret_cast<__bf16*>(scr + S_HV);
-    float* lg = reinterpret_cast<float*>(scr + S_LG);
-    float* vp = reinterpret_cast<float*>(scr + S_VP);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5;
 
-    // zero everything once: padding cells and the k-padding of hp / hv are never written again
+    // zero everything once: padding cells and the k-padding of the head planes are never written again
     {
         uint4* z = reinterpret_cast<uint4*>(lds);
         for (int i = tid; i < LDS_BYTES / 16; i += NTHREADS) z[i] = make_uint4(0, 0, 0, 0);
@@ -228,44 +229,48 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
     }
     __syncthreads();
     if (tid < 100) sbias[tid] = reinterpret_cast<const float*>(blob + OFF_BIAS)[tid];
-    __syncthreads();
+    if (tid < 256) {
+        reinterpret_cast<float*>(scr + S_B1)[tid] = reinterpret_cast<const float*>(blob + OFF_B1)[tid];
+        reinterpret_cast<float*>(scr + S_W2)[tid] = reinterpret_cast<const float*>(blob + OFF_W2)[tid];
+    }
+    if (tid < 64) reinterpret_cast<float*>(scr + S_BP)[tid] = reinterpret_cast<const float*>(blob + OFF_BP)[tid];
 
-    // ---- which leaves does this workgroup evaluate?  Only leaves that need the network
-    // (kind EVAL or ROOT in leaf_info) are packed, 16 per tile; tile t goes to workgroup
-    // t % gridDim.  Every workgroup scans the (L2-resident) leaf_info array itself, so the
-    // compaction costs no extra launch and no atomics, and the packing order is deterministic.
+    // ---- which leaves does each wave evaluate?  Only leaves that need the network (kind EVAL or
+    // ROOT in leaf_info) are packed, two per wave-task; task t goes to wave slot t % (8*gridDim),
+    // slot s = workgroup s % gridDim, wave s / gridDim, so a partial last round is spread over all
+    // CUs.  Every workgroup scans the (L2-resident) leaf_info array itself: no extra launch, no
+    // atomics, deterministic packing order.
     int* tlist = reinterpret_cast<int*>(scr + S_TL);
     int* wtot = reinterpret_cast<int*>(scr + S_WT);
-    if (tid < MAX_LIST) tlist[tid] = -1;
+    if (tid < 8 * MAXIT * 2) tlist[tid] = -1;
     __syncthreads();
-    int total;
+    const int NW = (int)gridDim.x * 8;
     if (!leaf_info) {
-        // dense mode: every leaf is evaluated, tile t = leaves [16t, 16t+16)
-        total = n;
-        int k = 0;
-        for (int tile = blockIdx.x; tile * TB < n && k * TB < MAX_LIST; tile += gridDim.x, ++k)
-            if (tid < TB && tile * TB + tid < n) tlist[k * TB + tid] = tile * TB + tid;
+        // dense mode: every leaf is evaluated, task t = leaves 2t, 2t+1
+        if (tid < 8 * MAXIT * 2) {
+            const int w = tid / (MAXIT * 2), k = (tid >> 1) % MAXIT;
+            const int leaf = 2 * ((int)blockIdx.x + (int)gridDim.x * w + NW * k) + (tid & 1);
+            if (leaf < n) tlist[tid] = leaf;
+        }
     } else {
         // thread t owns games [t*per, t*per + per); `per` is rounded up to a multiple of 4 so the
         // kinds arrive as 16-byte loads, and the "needs eval" flags stay in a register mask
         const int per = ((n + NTHREADS - 1) / NTHREADS + 3) & ~3;
         const int g0 = tid * per;
         unsigned long long mask = 0;           // up to 64 games per thread (n <= 32768)
-        {
-            for (int j = 0; j < per; j += 4) {
-                const int g = g0 + j;
-                int4 k4 = make_int4(0, 0, 0, 0);
-                if (g + 3 < n) k4 = *reinterpret_cast<const int4*>(leaf_info + g);
-                else {
-                    if (g < n) k4.x = leaf_info[g];
-                    if (g + 1 < n) k4.y = leaf_info[g + 1];
-                    if (g + 2 < n) k4.z = leaf_info[g + 2];
-                }
-                const int ks[4] = {k4.x & 0xFF, k4.y & 0xFF, k4.z & 0xFF, k4.w & 0xFF};
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (ks[i] == AZ_LEAF_EVAL || ks[i] == AZ_LEAF_ROOT) mask |= 1ull << (j + i);
+        for (int j = 0; j < per; j += 4) {
+            const int g = g0 + j;
+            int4 k4 = make_int4(0, 0, 0, 0);
+            if (g + 3 < n) k4 = *reinterpret_cast<const int4*>(leaf_info + g);
+            else {
+                if (g < n) k4.x = leaf_info[g];
+                if (g + 1 < n) k4.y = leaf_info[g + 1];
+                if (g + 2 < n) k4.z = leaf_info[g + 2];
             }
+            const int ks[4] = {k4.x & 0xFF, k4.y & 0xFF, k4.z & 0xFF, k4.w & 0xFF};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (ks[i] == AZ_LEAF_EVAL || ks[i] == AZ_LEAF_ROOT) mask |= 1ull << (j + i);
         }
         const int cnt = __popcll(mask);
         int incl = cnt;
@@ -276,38 +281,44 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
         }
         if (lane == 63) wtot[wave] = incl;
         __syncthreads();
-        int before = 0;
-        total = 0;
+        int before = 0, total = 0;
 #pragma unroll
         for (int w = 0; w < 8; ++w) {
             const int t = wtot[w];
             before += (w < wave) ? t : 0;
             total += t;
         }
-        // ranks [rank0, rank0 + cnt) belong to this thread; only the few threads whose ranks
-        // fall into one of this workgroup's tiles have anything to write
-        const int rank0 = before + incl - cnt;
-        const int ntl = (total + TB - 1) / TB;
-        int k = 0;
-        for (int tile = blockIdx.x; tile < ntl; tile += gridDim.x, ++k) {
-            const int lo = tile * TB;
-            if (rank0 + cnt <= lo || rank0 >= lo + TB || k * TB >= MAX_LIST) continue;
-            unsigned long long m = mask;
-            int rank = rank0;
-            while (m) {
-                const int j = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                if (rank >= lo && rank < lo + TB) tlist[k * TB + rank - lo] = g0 + j;
-                ++rank;
+        // ranks [rank0, rank0 + cnt) belong to this thread.  gridDim is a power of two (log2 in
+        // grid_shift), so "is task t mine" is a mask test.
+        int rank = before + incl - cnt;
+        (void)total;
+        while (mask) {
+            const int j = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const int t = rank >> 1;
+            if ((t & ((int)gridDim.x - 1)) == (int)blockIdx.x) {
+                const int w = (t >> grid_shift) & 7, k = t >> (grid_shift + 3);
+                if (k < MAXIT) tlist[(w * MAXIT + k) * 2 + (rank & 1)] = g0 + j;
             }
+            ++rank;
         }
     }
     __syncthreads();
 
-    const int ntiles = (total + TB - 1) / TB;
-    int iter = 0;
-    for (int bt = blockIdx.x; bt < ntiles; bt += gridDim.x, ++iter) {
-        const int* games = tlist + iter * TB;
+    // ---- from here on every wave is on its own: it takes two leaves at a time through the whole
+    // network inside its two boards of the LDS images and its own head scratch; no workgroup barrier.
+    uint8_t* pw = scr + S_PW + wave * PW_BYTES;
+    __bf16* hp = reinterpret_cast<__bf16*>(pw + PW_HP);
+    __bf16* hv = reinterpret_cast<__bf16*>(pw + PW_HV);
+    float* lg = reinterpret_cast<float*>(pw + PW_LG);
+    const float* sb1 = reinterpret_cast<const float*>(scr + S_B1);
+    const float* sw2 = reinterpret_cast<const float*>(scr + S_W2);
+    const float* sbp = reinterpret_cast<const float*>(scr + S_BP);
+    const int* mylist = tlist + wave * MAXIT * 2;
+
+    for (int iter = 0; iter < MAXIT; ++iter) {
+        const int games[2] = {mylist[2 * iter], mylist[2 * iter + 1]};
+        if (games[0] < 0) break;
         const uint8_t* sblob = blob;
         asm volatile("" : "+s"(sblob));
         stem(sblob, leaf_bb, games, bufY, sbias, wave, lane);
@@ -316,9 +327,9 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
             conv3x3<true>(w2, bufX, bufY, sbias + 64, wave, lane);
         }
 
-        // Head weights are fetched here, per iteration: hoisted above the loop they would be
-        // spilled to scratch (the tower owns the register file).  The empty asm makes the
-        // pointer opaque so the loads stay below this point.
+        // Head weights are fetched here, per task: hoisted above the loop they would be spilled to
+        // scratch (the tower owns the register file).  The empty asm makes the pointer opaque so the
+        // loads stay below this point.
         const uint8_t* hblob = blob;
         asm volatile("" : "+s"(hblob));
         // ---- 1x1 head convs as one 2-step MFMA: rows 0,1 = policy planes, row 2 = value plane
@@ -334,66 +345,69 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
                 for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
                 acc = MFMA(a0, *reinterpret_cast<const bf16x8*>(base), acc);
                 acc = MFMA(a1, *reinterpret_cast<const bf16x8*>(base + 32), acc);
-                const int y = o >> 3, x = o & 7;
+                const int y = o >> 3, x = o & 7, bl = b - 2 * wave;
                 if (h == 0 && x != 7) {
                     const int cell = y * 7 + x;
-                    hp[b * 96 + cell] = (__bf16)fmaxf(acc[0] + sbias[96], 0.0f);
-                    hp[b * 96 + 42 + cell] = (__bf16)fmaxf(acc[1] + sbias[97], 0.0f);
-                    hv[b * 48 + cell] = (__bf16)fmaxf(acc[2] + sbias[98], 0.0f);
+                    hp[bl * 96 + cell] = (__bf16)fmaxf(acc[0] + sbias[96], 0.0f);
+                    hp[bl * 96 + 42 + cell] = (__bf16)fmaxf(acc[1] + sbias[97], 0.0f);
+                    hv[bl * 48 + cell] = (__bf16)fmaxf(acc[2] + sbias[98], 0.0f);
                 }
             }
         }
-        __syncthreads();
-
-        // ---- value FC 42->256 (+ReLU) and 256->1: wave w owns hidden units 32w..32w+31
+        const int bcol = lane & 1;             // MFMA columns 2..31 duplicate the two boards and are ignored
+        // ---- value head: FC 42->256 (+ReLU) as 8 row tiles, then 256->1 and tanh
         {
-            const int bcol = lane & 15;         // columns 16..31 duplicate boards 0..15 and are ignored
-            f32x16 acc;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-#pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                const bf16x8 a = frag_ptr(hblob, OFF_F1 + (wave * 3 + s) * 1024, lane)[0];
-                const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(hv + bcol * 48 + 16 * s + 8 * h);
-                acc = MFMA(a, bfr, acc);
-            }
-            const float* b1 = reinterpret_cast<const float*>(hblob + OFF_B1) + 32 * wave;
-            const float* w2v = reinterpret_cast<const float*>(hblob + OFF_W2) + 32 * wave;
             float part = 0.0f;
+#pragma unroll 2
+            for (int t = 0; t < 8; ++t) {
+                f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                part = fmaf(fmaxf(acc[r] + b1[row], 0.0f), w2v[row], part);
+                for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const bf16x8 a = frag_ptr(hblob, OFF_F1 + (t * 3 + s) * 1024, lane)[0];
+                    const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(hv + bcol * 48 + 16 * s + 8 * h);
+                    acc = MFMA(a, bfr, acc);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(sb1 + 32 * t + 8 * g + 4 * h);
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(sw2 + 32 * t + 8 * g + 4 * h);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) part = fmaf(fmaxf(acc[4 * g + i] + b1[i], 0.0f), wv[i], part);
+                }
             }
             part += __shfl_xor(part, 32);
-            if (lane < 32) vp[wave * 32 + lane] = part;
+            if (lane < 2 && games[lane] >= 0)
+                v_out[games[lane]] = tanhf(part + reinterpret_cast<const float*>(hblob + OFF_B2)[0]);
         }
-        // ---- policy FC 84->42: waves 0,1 own cells 0..31 / 32..41
-        if (wave < 2) {
-            const int bcol = lane & 15;
+        // ---- policy head: FC 84->42 as 2 row tiles (cells 0..31, 32..41)
+#pragma unroll 1
+        for (int t = 0; t < 2; ++t) {
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
 #pragma unroll
             for (int s = 0; s < 6; ++s) {
-                const bf16x8 a = frag_ptr(hblob, OFF_PF + (wave * 6 + s) * 1024, lane)[0];
+                const bf16x8 a = frag_ptr(hblob, OFF_PF + (t * 6 + s) * 1024, lane)[0];
                 const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(hp + bcol * 96 + 16 * s + 8 * h);
                 acc = MFMA(a, bfr, acc);
             }
-            if ((lane & 31) < 16) {
-                const float* bp = reinterpret_cast<const float*>(hblob + OFF_BP) + 32 * wave;
+            if ((lane & 31) < 2) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    lg[bcol * 64 + 32 * wave + row] = acc[r] + bp[row];
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bp = *reinterpret_cast<const f32x4*>(sbp + 32 * t + 8 * g + 4 * h);
+                    f32x4 o4;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o4[i] = acc[4 * g + i] + bp[i];
+                    *reinterpret_cast<f32x4*>(lg + bcol * 64 + 32 * t + 8 * g + 4 * h) = o4;
                 }
             }
         }
-        __syncthreads();
-
-        if (tid < TB * 8) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // lg written by lanes 0,1,32,33, read below
+        if (lane < 16) {
             // landing-cell gather (connectfour.py:56-71) + soft-max over legal columns (mcts.py:106)
-            const int b = tid >> 3, c = tid & 7;
+            const int b = lane >> 3, c = lane & 7;
             const int gidx = games[b];
             uint64_t occ = 0;
             if (gidx >= 0) occ = leaf_bb[2 * (size_t)gidx] | leaf_bb[2 * (size_t)gidx + 1];
@@ -406,14 +420,7 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
             float sum = e;
             sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
             if (c < 7 && gidx >= 0) p_out[(size_t)gidx * 7 + c] = legal ? e / sum : 0.0f;
-        } else if (tid >= 256 && tid < 256 + TB) {
-            const int b = tid - 256, gidx = games[b];
-            float s = reinterpret_cast<const float*>(hblob + OFF_B2)[0];
-#pragma unroll
-            for (int w = 0; w < 8; ++w) s += vp[w * 32 + b];
-            if (gidx >= 0) v_out[gidx] = tanhf(s);
         }
-        // the next iteration's stem writes bufY only; hp/hv/lg/vp are rewritten after >= 2 barriers
     }
 }
 
@@ -432,11 +439,15 @@ int az_c4net_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uint64_
             return -2;
         attr_set = true;
     }
-    int ntiles = (n + TB - 1) / TB;
-    int grid = ntiles < 256 ? ntiles : 256;      // one persistent workgroup per CU
-    if (n > 32768) return -4;                    // the in-kernel packing handles up to 64 leaves per thread
+    // one persistent workgroup per CU at most; a power of two so tasks map to waves by bit masks; with
+    // fewer tasks than wave slots the tasks are spread one per CU first (slot s = WG s % grid)
+    const int ntasks = (n + 1) / 2;
+    int grid_shift = 0;
+    while ((1 << grid_shift) < ntasks && grid_shift < 8) ++grid_shift;
+    const int grid = 1 << grid_shift;
+    if (n > 32768) return -4;                    // MAXIT wave-tasks per wave, 64 leaves per scanning thread
     hipLaunchKernelGGL(k_c4net_bf16, dim3(grid), dim3(NTHREADS), LDS_BYTES, (hipStream_t)stream, blob, (int)num_blocks,
-                       leaf_bb, leaf_info, (int)n, p, v);
+                       leaf_bb, leaf_info, (int)n, p, v, grid_shift);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

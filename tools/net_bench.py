@@ -14,18 +14,19 @@ from alphazero_amd.models import AlphaZeroC4
 from alphazero_amd.net import FusedC4Net
 
 ap = argparse.ArgumentParser()
-ap.add_argument('--n', type=int, default=8192)
+ap.add_argument('--n', type=str, default='8192')
 ap.add_argument('--blocks', type=str, default='6')
 ap.add_argument('--ch', type=int, default=32)
 ap.add_argument('--iters', type=int, default=50)
 args = ap.parse_args()
 
 rng = np.random.RandomState(0)
-hists = [list(rng.randint(0, 7, size=rng.randint(0, 6))) for _ in range(args.n)]
-bb, nm = E.positions_from_history(1, hists)
-legal, _, _ = E.game_query(1, bb, nm)
-info = ((legal << 16) | 1).to(torch.int32)
-for blocks in [int(b) for b in args.blocks.split(',')]:
+for n_, blocks in [(int(a), int(b)) for a in args.n.split(',') for b in args.blocks.split(',')]:
+    args.n = n_
+    hists = [list(rng.randint(0, 7, size=rng.randint(0, 6))) for _ in range(args.n)]
+    bb, nm = E.positions_from_history(1, hists)
+    legal, _, _ = E.game_query(1, bb, nm)
+    info = ((legal << 16) | 1).to(torch.int32)
     torch.manual_seed(0)
     net = FusedC4Net.from_module(AlphaZeroC4(blocks, args.ch).eval(), 'cuda')
     flops = args.n * (2 * blocks * 2 * 9 * args.ch * args.ch * 42 + 2 * 9 * 2 * args.ch * 42)
