@@ -20,6 +20,7 @@
 // The file is compiled with -ffp-contract=off: a fused multiply-add anywhere in
 // the score would change roundings and, eventually, visit counts.
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -48,22 +49,23 @@ static int fail(const char* what, hipError_t e = hipSuccess) {
 // device-side state
 // ---------------------------------------------------------------------------
 struct __attribute__((aligned(128))) Slot {
+    // hot header, 64 B: every simulation kernel reads it with four 16-byte loads
     uint64_t nx, pv;                 // root position
-    uint64_t uid;
     uint64_t leaf_nx, leaf_pv;       // pending leaf position
-    uint64_t st_sims, st_steps, st_evals, st_root_evals, st_moves, st_games;
+    uint32_t root, alloc;
     int32_t  nm;
-    uint32_t root;
-    uint32_t alloc;
-    int32_t  leaf_kind;
-    int32_t  leaf_depth;
-    int32_t  leaf_nm;
-    uint32_t err;
-    uint32_t move_sims;
+    uint32_t root_ns;                // sum N of the root: a prefetch hint, always validated
+    int32_t  leaf_kind, leaf_depth;
+    uint32_t err, move_sims;
+    // counters, 64 B
+    uint64_t st_sims, st_steps, st_evals, st_root_evals, st_moves, st_games;
+    uint64_t uid;
+    int32_t  leaf_nm, pad0;
     uint32_t path[PATH_LEN];         // (node << 4) | slot per select level
     uint8_t  hist[HIST_PAD];
     uint8_t  nedges[HIST_PAD];
 };
+static_assert(offsetof(Slot, st_sims) == 64 && offsetof(Slot, path) == 128, "Slot layout");
 
 struct Dev {
     uint4*          pool;       // [G][cap][A+1]
@@ -128,14 +130,17 @@ __device__ __forceinline__ double puct_score(uint32_t N, float W, float P, doubl
     return (double)Q + U;
 }
 
+// beyond the host table: device libm (not bit-pinned to numpy); kept out of line
+__device__ __noinline__ double2 lut_slow(double c_base, double c_init, uint32_t Ns) {
+    return make_double2(log((double)(1ull + Ns + (uint64_t)c_base) / c_base) + c_init, sqrt((double)Ns));
+}
+__device__ __forceinline__ double2 lut_fetch(const Dev& E, uint32_t Ns) {
+    if ((int32_t)Ns >= 0 && (int32_t)Ns < E.lut_len) return E.lut[Ns];
+    return lut_slow(E.c_base, E.c_init, Ns);
+}
 __device__ __forceinline__ void lut_lookup(const Dev& E, uint32_t Ns, double& cs, double& sq) {
-    if ((int32_t)Ns < E.lut_len) {
-        const double2 t = E.lut[Ns];
-        cs = t.x; sq = t.y;
-    } else {  // beyond the host table: device libm (not bit-pinned to numpy)
-        cs = log((double)(1ull + Ns + (uint64_t)E.c_base) / E.c_base) + E.c_init;
-        sq = sqrt((double)Ns);
-    }
+    const double2 t = lut_fetch(E, Ns);
+    cs = t.x; sq = t.y;
 }
 
 // ---------------------------------------------------------------------------
@@ -414,6 +419,7 @@ k_choose(Dev E, const double* u_in, int32_t* out_action, int32_t* out_nedges, ui
         }
     } else if (lane == 0) {
         s->nx = nx; s->pv = pv; s->nm = nm;
+        s->root_ns = rdlane(N, slot) - 1u;                  // prefetch hint for the new root's sum N
         if (E.reuse) s->root = child;                       // selfplay.py:35-36
         else { s->root = AZ_NO_NODE; s->alloc = 0; }        // selfplay.py:38
         s->st_moves += 1; s->leaf_kind = AZ_LEAF_NONE; s->move_sims = 0;
@@ -448,31 +454,40 @@ struct Grp {
     }
 };
 
-// mcts.py:119-134 for the group's tree; path[] is this game's row of the block's LDS path stack
+// mcts.py:119-134 for the group's tree; path[] is this game's row of the block's LDS path stack.
+// ns_hint: expected sum N of the root.  The {Cs, sqrt(Ns)} entry of a node is fetched together
+// with the node itself, for the sum N the node is expected to have (a child reached through an
+// edge with N visits was expanded on the first of them, so its edges sum to N-1); the entry is
+// re-fetched if the node's own sum differs, so the hint never affects results.
 template <class GM, int GS>
 __device__ __forceinline__ void select_leaf_g(const Dev& E, const uint4* pool, uint32_t root, uint64_t& nx,
                                               uint64_t& pv, int& nm, uint32_t* path, int sub, int& kind,
-                                              int& depth, float& vterm, uint32_t& steps) {
+                                              int& depth, float& vterm, uint32_t& steps, uint32_t& ns_hint) {
     constexpr int AS = GM::A + 1;
     static_assert(AS <= GS, "group too small for this game");
     using G_ = Grp<GS>;
     kind = AZ_LEAF_NONE; depth = 0; vterm = 0.0f;
     uint32_t node = root;
     bool active = root != AZ_NO_NODE && GM::winner(nx, pv, nm) == AZ_W_NONE;
+    uint32_t hint = ns_hint;
+    double2 lt = make_double2(0.0, 0.0);
+    if (active) lt = lut_fetch(E, hint);
     while (active) {
         uint4 e = make_uint4(0u, 0u, 0u, AZ_NO_NODE);
         if (sub < AS) e = pool[(size_t)node * AS + sub];
         const int n_edges = (int)G_::bcast(e.x, AS - 1);
         const uint32_t Ns = G_::bcast(e.y, AS - 1);
-        double cs, sq;
-        lut_lookup(E, Ns, cs, sq);
+        if (Ns != hint) lt = lut_fetch(E, Ns);
+        if (depth == 0) ns_hint = Ns + 1u;                             // this simulation adds one root visit
         const bool act = sub < n_edges;
         double score = -INFINITY;
-        if (act) score = puct_score(e.x, __uint_as_float(e.y), __uint_as_float(e.z), cs, sq);
+        if (act) score = puct_score(e.x, __uint_as_float(e.y), __uint_as_float(e.z), lt.x, lt.y);
         const double mx = G_::gmax(score);
         const uint32_t hit = G_::gballot(act && score == mx);
         const int slot = __ffs((int)hit) - 1;                          // np.argmax: first maximum
         const uint32_t child = G_::bcast(e.w, slot);
+        hint = G_::bcast(e.x, slot) - 1u;
+        if (child != AZ_NO_NODE) lt = lut_fetch(E, hint);              // in flight with the child's line
         const int action = az_nth_set_bit(GM::legal(nx, pv), slot);    // mcts.py:126
         if (sub == 0) path[depth] = (node << 4) | (uint32_t)slot;
         depth += 1;
@@ -514,22 +529,25 @@ __device__ __forceinline__ uint32_t expand_node_g(const Dev& E, uint4* pool, uin
     return idx;
 }
 
+// mcts.py:84-86 for one path level: W += v (fp32), N += 1, and the node's cached sum N
+template <class GM>
+__device__ __forceinline__ void backup_edge(uint4* pool, uint32_t ent, float v) {
+    constexpr int AS = GM::A + 1;
+    const uint32_t node = ent >> 4, slot = ent & 15u;
+    uint2* ep = reinterpret_cast<uint2*>(&pool[(size_t)node * AS + slot]);
+    uint32_t* ns = reinterpret_cast<uint32_t*>(&pool[(size_t)node * AS + AS - 1]) + 1;
+    uint2 nw = *ep;                       // both loads are issued before either store
+    const uint32_t nsv = *ns;
+    nw.x += 1u;
+    nw.y = __float_as_uint(__uint_as_float(nw.y) + v);
+    *ep = nw;
+    *ns = nsv + 1u;
+}
 // mcts.py:147-158: the group's lanes take path levels sub, sub+GS, ... (levels are distinct nodes)
 template <class GM, int GS>
 __device__ __forceinline__ void backup_g(uint4* pool, int depth, const uint32_t* path, float v_leaf_edge, int sub) {
-    constexpr int AS = GM::A + 1;
-    for (int d = sub; d < depth; d += GS) {
-        const uint32_t ent = path[d];
-        const uint32_t node = ent >> 4, slot = ent & 15u;
-        const float v = ((depth - 1 - d) & 1) ? -v_leaf_edge : v_leaf_edge;
-        uint2* ep = reinterpret_cast<uint2*>(&pool[(size_t)node * AS + slot]);
-        uint2 nw = *ep;
-        nw.x += 1u;
-        nw.y = __float_as_uint(__uint_as_float(nw.y) + v);
-        *ep = nw;
-        uint32_t* ns = reinterpret_cast<uint32_t*>(&pool[(size_t)node * AS + AS - 1]) + 1;
-        *ns += 1u;
-    }
+    for (int d = sub; d < depth; d += GS)
+        backup_edge<GM>(pool, path[d], ((depth - 1 - d) & 1) ? -v_leaf_edge : v_leaf_edge);
 }
 
 #define GROUP_PROLOGUE                                                                   \
@@ -543,36 +561,74 @@ __device__ __forceinline__ void backup_g(uint4* pool, int depth, const uint32_t*
     uint4* pool = E.pool + (size_t)g * E.cap * (GM::A + 1);                              \
     uint32_t* path = lds_path[gl];
 
-// mcts.py:119-158, one simulation per game per launch (see k_sim_step), GS lanes per game
+// mcts.py:119-158, one simulation per game per launch, GS lanes per game:
+//   DO_EXPAND: finish the pending simulation with the evaluator's (p, v);
+//   DO_SELECT: start the next one; terminal leaves are backed up at once.
+// Everything the kernel needs from the slot, the saved path and (p, v) is requested up front in one
+// batch of loads, so the dependent chain is: slot -> edges to back up -> root -> one line per level.
 template <class GM, int GS, bool DO_EXPAND, bool DO_SELECT>
 __global__ void __launch_bounds__(BLOCK_THREADS)
 k_sim_step_p(Dev E, const float* p, const float* v, uint64_t* leaf_bb, int32_t* leaf_info) {
     GROUP_PROLOGUE
-    uint32_t alloc = s->alloc, err = s->err;
-    const uint32_t root = s->root;
+    using G_ = Grp<GS>;
+    constexpr int AS = GM::A + 1;
+    const uint4* sh = reinterpret_cast<const uint4*>(s);
+    const uint4 h0 = sh[0], h1 = sh[1], h2 = sh[2], h3 = sh[3];
+    const uint4 c0 = sh[4], c1 = sh[5];                              // st_sims, st_steps | st_evals, st_root_evals
+    uint32_t pa = 0, pb = 0;
+    float p_lane = 0.0f, v_g = 0.0f;
+    if (DO_EXPAND) {
+        pa = s->path[sub];                                           // levels 0..GS-1 and GS..2GS-1
+        if (GS < PATH_LEN && sub + GS < PATH_LEN) pb = s->path[sub + GS];
+        if (sub < GM::A) p_lane = p[(size_t)g * GM::A + sub];
+        v_g = v[g];
+    }
+    uint64_t nx = (uint64_t)h0.x | ((uint64_t)h0.y << 32), pv = (uint64_t)h0.z | ((uint64_t)h0.w << 32);
+    const uint64_t leaf_nx = (uint64_t)h1.x | ((uint64_t)h1.y << 32), leaf_pv = (uint64_t)h1.z | ((uint64_t)h1.w << 32);
+    const uint32_t root = h2.x;
+    uint32_t alloc = h2.y, root_ns = h2.w, err = h3.z;
+    int nm = (int)h2.z, kind = (int)h3.x;
     uint32_t sims = 0, evals = 0, steps = 0;
-    int kind = s->leaf_kind;
 
     if (DO_EXPAND && kind == AZ_LEAF_EVAL) {
-        const int depth = s->leaf_depth;
-        for (int d = sub; d < depth; d += GS) path[d] = s->path[d];
-        const uint32_t idx = expand_node_g<GM, GS>(E, pool, alloc, s->leaf_nx, s->leaf_pv, p + (size_t)g * GM::A, err, sub);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");        // path[] written by other lanes of the group
-        const uint32_t last = path[depth - 1];
-        if (idx != AZ_NO_NODE && sub == 0)
-            reinterpret_cast<uint32_t*>(&pool[(size_t)(last >> 4) * (GM::A + 1) + (last & 15u)])[3] = idx;
-        backup_g<GM, GS>(pool, depth, path, -v[g], sub);               // mcts.py:144
+        const int depth = (int)h3.y;
+        // mcts.py:20-26: the new node, priors compacted to the legal moves
+        uint32_t idx = AZ_NO_NODE;
+        if (alloc < (uint32_t)E.cap) { idx = alloc; alloc += 1; } else err |= 1u;
+        const uint32_t legal = GM::legal(leaf_nx, leaf_pv);
+        const int n_edges = az_popc32(legal);
+        const int my_action = sub < n_edges ? az_nth_set_bit(legal, sub) : 0;
+        const float pr = __uint_as_float(G_::bcast(__float_as_uint(p_lane), my_action));
+        if (idx != AZ_NO_NODE && sub < AS) {
+            uint4 rec = make_uint4(0u, 0u, sub < n_edges ? __float_as_uint(pr) : 0u, AZ_NO_NODE);
+            if (sub == AS - 1) rec = make_uint4((uint32_t)n_edges, 0u, 0u, 0u);
+            pool[(size_t)idx * AS + sub] = rec;
+        }
+        const int dl = depth - 1;
+        const uint32_t last = G_::bcast(dl < GS ? pa : pb, dl & (GS - 1));
+        if (2 * GS < PATH_LEN && depth > 2 * GS) { /* deeper than the two registers hold: rare, read it */
+            const uint32_t l2 = s->path[dl];
+            if (sub == 0 && idx != AZ_NO_NODE)
+                reinterpret_cast<uint32_t*>(&pool[(size_t)(l2 >> 4) * AS + (l2 & 15u)])[3] = idx;
+        } else if (idx != AZ_NO_NODE && sub == 0) {
+            reinterpret_cast<uint32_t*>(&pool[(size_t)(last >> 4) * AS + (last & 15u)])[3] = idx;
+        }
+        // mcts.py:144-158: v *= -1, then one level per lane
+        const float vb = -v_g;
+        if (sub < depth) backup_edge<GM>(pool, pa, ((depth - 1 - sub) & 1) ? -vb : vb);
+        if (GS < PATH_LEN && sub + GS < depth) backup_edge<GM>(pool, pb, ((depth - 1 - sub - GS) & 1) ? -vb : vb);
+        for (int d = sub + 2 * GS; d < depth; d += GS)
+            backup_edge<GM>(pool, s->path[d], ((depth - 1 - d) & 1) ? -vb : vb);
         sims += 1; evals += 1;
         kind = AZ_LEAF_NONE;
     }
-    if (DO_EXPAND && DO_SELECT) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    if (DO_EXPAND && DO_SELECT) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // own stores before re-reading nodes
 
+    int depth = 0;
     if (DO_SELECT) {
-        uint64_t nx = s->nx, pv = s->pv;
-        int nm = s->nm, depth;
         float vterm;
-        select_leaf_g<GM, GS>(E, pool, root, nx, pv, nm, path, sub, kind, depth, vterm, steps);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        select_leaf_g<GM, GS>(E, pool, root, nx, pv, nm, path, sub, kind, depth, vterm, steps, root_ns);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // path[] is written by lane 0 of the group
         if (kind == AZ_LEAF_TERMINAL) {
             backup_g<GM, GS>(pool, depth, path, vterm, sub);
             sims += 1;
@@ -580,14 +636,21 @@ k_sim_step_p(Dev E, const float* p, const float* v, uint64_t* leaf_bb, int32_t* 
             for (int d = sub; d < depth; d += GS) s->path[d] = path[d];
         }
         if (sub == 0) {
-            s->leaf_depth = depth; s->leaf_nx = nx; s->leaf_pv = pv; s->leaf_nm = nm;
             leaf_bb[2 * (size_t)g] = nx; leaf_bb[2 * (size_t)g + 1] = pv;
             leaf_info[g] = kind | (nm << 8) | ((int)GM::legal(nx, pv) << 16);
         }
     }
     if (sub == 0) {
-        s->leaf_kind = kind; s->alloc = alloc; s->err = err;
-        s->move_sims += sims; s->st_sims += sims; s->st_evals += evals; s->st_steps += steps;
+        uint4* so = reinterpret_cast<uint4*>(s);
+        if (DO_SELECT) so[1] = make_uint4((uint32_t)nx, (uint32_t)(nx >> 32), (uint32_t)pv, (uint32_t)(pv >> 32));
+        so[2] = make_uint4(root, alloc, h2.z, root_ns);
+        so[3] = make_uint4((uint32_t)kind, DO_SELECT ? (uint32_t)depth : h3.y, err, h3.w + sims);
+        const uint64_t st_sims = ((uint64_t)c0.x | ((uint64_t)c0.y << 32)) + sims;
+        const uint64_t st_steps = ((uint64_t)c0.z | ((uint64_t)c0.w << 32)) + steps;
+        const uint64_t st_evals = ((uint64_t)c1.x | ((uint64_t)c1.y << 32)) + evals;
+        so[4] = make_uint4((uint32_t)st_sims, (uint32_t)(st_sims >> 32), (uint32_t)st_steps, (uint32_t)(st_steps >> 32));
+        so[5] = make_uint4((uint32_t)st_evals, (uint32_t)(st_evals >> 32), c1.z, c1.w);
+        if (DO_SELECT) s->leaf_nm = nm;
     }
 }
 
@@ -599,13 +662,13 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_run_uniform_p(Dev E, int num_
     const uint32_t root = s->root;
     const uint64_t nx0 = s->nx, pv0 = s->pv;
     const int nm0 = s->nm;
-    uint32_t sims = 0, evals = 0, steps = 0;
+    uint32_t sims = 0, evals = 0, steps = 0, root_ns = s->root_ns;
     if (root == AZ_NO_NODE) return;
     for (int it = 0; it < num_sims; ++it) {
         uint64_t nx = nx0, pv = pv0;
         int nm = nm0, depth, kind;
         float vterm;
-        select_leaf_g<GM, GS>(E, pool, root, nx, pv, nm, path, sub, kind, depth, vterm, steps);
+        select_leaf_g<GM, GS>(E, pool, root, nx, pv, nm, path, sub, kind, depth, vterm, steps, root_ns);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         if (kind == AZ_LEAF_EVAL) {
             const uint32_t idx = expand_node_g<GM, GS>(E, pool, alloc, nx, pv, nullptr, err, sub);
@@ -621,7 +684,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_run_uniform_p(Dev E, int num_
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");        // own stores before next select's loads
     }
     if (sub == 0) {
-        s->alloc = alloc; s->err = err; s->leaf_kind = AZ_LEAF_NONE;
+        s->alloc = alloc; s->err = err; s->leaf_kind = AZ_LEAF_NONE; s->root_ns = root_ns;
         s->move_sims += sims; s->st_sims += sims; s->st_evals += evals; s->st_steps += steps;
     }
 }
