@@ -140,3 +140,66 @@ class FusedC4Net:
         check(self.lib.az_c4net_bf16_forward(ptr(self.blob), self.num_blocks, ptr(leaf_bb), ptr(leaf_info),
                                              n, ptr(self._p), ptr(self._v), st))
         return self._p, self._v
+
+
+def pack_c4_blob_f32(model):
+    """AlphaZeroC4 module -> float32 tensor in the layout of csrc/az_net_f32.hip (BN folded in
+    float64, then rounded once to float32)."""
+    C_ = model.block_channels
+    if C_ > CMAX or tuple(model.shape_in) != (2, 6, 7):
+        raise ValueError('fused fp32 kernel: Connect Four nets with up to 32 trunk channels')
+    dev = model._cbr[0].weight.device
+    z = lambda *shape: torch.zeros(*shape, dtype=torch.float64, device=dev)
+    with torch.no_grad():
+        bias = z(3, 32)
+        w, b = _fold_bn(model._cbr[0].weight, model._cbr[1])
+        stem = z(18, 32)
+        stem[:, :C_] = w.permute(2, 3, 1, 0).reshape(18, C_)            # k = tap*2 + plane
+        bias[0, :C_] = b
+        convs = [z(288, 32), z(288, 32)]
+        if len(model._tower):
+            blk = model._tower[0]
+            for i, (cv, bn) in enumerate(((blk._c1, blk._bn1), (blk._c2, blk._bn2))):
+                w, b = _fold_bn(cv.weight, bn)
+                m = z(9, 32, 32)
+                m[:, :C_, :C_] = w.permute(2, 3, 1, 0).reshape(9, C_, C_)   # [tap][ci][co]
+                convs[i] = m.reshape(288, 32)
+                bias[1 + i, :C_] = b
+        ph, vh = model._policy_head, model._value_head
+        wpol, bpol = _fold_bn(ph._cbr[0].weight, ph._cbr[1], ph._cbr[0].bias)
+        wval, bval = _fold_bn(vh._cbr[0].weight, vh._cbr[1])
+        hw = z(3, 32)
+        hw[0:2, :C_] = wpol[:, :, 0, 0]
+        hw[2, :C_] = wval[0, :, 0, 0]
+        hb = torch.cat([bpol[:2], bval[:1], z(1)])
+        bp = torch.cat([ph._fc.bias.double(), z(2)])
+        parts = [stem, convs[0], convs[1], bias, hw, hb, ph._fc.weight.double(), bp,
+                 vh._fc[0].weight.double().t().contiguous(), vh._fc[0].bias.double(), vh._fc[2].weight.double(),
+                 torch.cat([vh._fc[2].bias.double().reshape(1), z(3)])]
+        blob = torch.cat([t.reshape(-1) for t in parts]).float().contiguous()
+    assert blob.numel() == _lib.load().az_c4net_f32_blob_floats(), blob.numel()
+    return blob
+
+
+class FusedC4NetF32:
+    """fp32 parity evaluator: net(leaf_bb, leaf_info) -> (p, v); evaluates every leaf."""
+
+    def __init__(self, model, device=None):
+        self.lib = _lib.load()
+        self.device = torch.device(device if device is not None else next(model.parameters()).device)
+        self.num_blocks = model.num_blocks
+        self.blob = pack_c4_blob_f32(model).to(self.device)
+        self._p = self._v = None
+
+    def load_module(self, model):
+        self.blob.copy_(pack_c4_blob_f32(model))
+
+    def __call__(self, leaf_bb, leaf_info=None):
+        n = leaf_bb.shape[0]
+        if self._p is None or self._p.shape[0] != n:
+            self._p = torch.empty(n, 7, dtype=torch.float32, device=self.device)
+            self._v = torch.empty(n, dtype=torch.float32, device=self.device)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(self.lib.az_c4net_f32_forward(ptr(self.blob), self.num_blocks, ptr(leaf_bb), n,
+                                            ptr(self._p), ptr(self._v), st))
+        return self._p, self._v

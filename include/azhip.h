@@ -187,6 +187,14 @@ int  az_c4net_blob_bytes(void);
 int  az_c4net_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uint64_t* leaf_bb,
                            const int32_t* leaf_info, int32_t n, float* p, float* v, void* stream);
 
+/* Same network entirely in fp32 (weights, activations, accumulation; trunk on
+ * v_mfma_f32_32x32x2_f32): the parity path, agrees with the fp32 torch statement to ~1e-6.
+ * blob = DEVICE float buffer of az_c4net_f32_blob_floats() floats (alphazero_amd/net.py
+ * pack_c4_blob_f32).  Evaluates every one of the n leaves.                                */
+int  az_c4net_f32_blob_floats(void);
+int  az_c4net_f32_forward(const float* blob, int32_t num_blocks, const uint64_t* leaf_bb, int32_t n,
+                          float* p, float* v, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,3 +88,31 @@ def test_fused_forward_packs_only_leaves_that_need_eval():
         act = (kind == 1) | (kind == 3)
         assert torch.equal(p[act], dense_p[act]) and torch.equal(v[act], dense_v[act])
         assert torch.all(p[~act] == -7.0) and torch.all(v[~act] == -7.0)
+
+
+@pytest.mark.parametrize('blocks,ch,n', [(6, 32, 777), (2, 8, 40), (0, 16, 9), (1, 26, 64), (3, 31, 100)])
+def test_fused_fp32_forward_matches_torch_fp32(blocks, ch, n):
+    """fp32 parity path: net outputs within 1e-5 relative of the fp32 torch statement (p and v are
+    O(1); an absolute floor of 1e-6 covers probabilities near zero)."""
+    from alphazero_amd import engine as E
+    from alphazero_amd.models import AlphaZeroC4
+    from alphazero_amd.net import FusedC4NetF32
+    torch.manual_seed(blocks * 10 + ch)
+    model = AlphaZeroC4(blocks, ch).eval()
+    _randomize_bn(model, 6)
+    hists = _random_positions(n, 12)
+    bb, nm = E.positions_from_history(1, hists)
+    net = FusedC4NetF32(model, 'cuda')
+    p, v = net(bb)
+    p, v = p.cpu(), v.cpu()
+    x, valid = E.render(1, bb)
+    with torch.no_grad():
+        logits, vref = model(x.cpu(), valid.cpu())
+    valid = valid.cpu()
+    pref = torch.zeros_like(logits)
+    for i in range(n):
+        pref[i, valid[i]] = torch.softmax(logits[i, valid[i]], 0)
+    assert torch.all(p[~valid] == 0)
+    assert torch.allclose(p, pref, rtol=1e-5, atol=1e-6), (p - pref).abs().max().item()
+    assert torch.allclose(v, vref.reshape(-1), rtol=1e-5, atol=1e-6), (v - vref.reshape(-1)).abs().max().item()
+    print('fp32 max |dp|', (p - pref).abs().max().item(), 'max |dv|', (v - vref.reshape(-1)).abs().max().item())
