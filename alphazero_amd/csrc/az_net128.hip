@@ -1,0 +1,315 @@
+// az_net128.hip -- 128-channel Connect Four trunk on bf16 MFMA (gfx950), layer by layer.
+//
+// The 10x128 network (alphazero/models.py:70-87 with block_channels = 128) has 295 KB of bf16
+// weights per 3x3 conv: they fit neither registers nor LDS, so unlike the 32-channel kernel
+// (az_net.hip) the trunk runs as one launch per conv with bf16 activations in HBM.  Per conv the
+// algorithmic work is 2*9*128*128*42 = 12.4 MFLOP per leaf against 2*56*256 B of activation
+// traffic, i.e. ~430 FLOP/B: matrix-core bound.
+//
+// Activation tensor: [1 guard][board][8 rows x 8 cols][128 ch] bf16, row 0 and row 7 of every
+// board and column 7 of every row are zero, so a 3x3 tap is a constant position offset (the same
+// trick as the LDS image of az_net.hip).  A workgroup (8 waves) computes 4 boards x 48 positions
+// x 128 output channels: the input slab (258 positions incl. halo) is staged in LDS once, the
+// weights stream through LDS one tap (128x128) at a time, double buffered, and every wave owns a
+// 32-channel x 96-position output block (3 accumulators), so one A fragment feeds 3 MFMAs.
+// D[co][pos] orientation puts 4 consecutive channels of one position in 4 registers: the epilogue
+// (bias, residual, ReLU, bf16) stores 8 bytes per lane.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/azhip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define CH 128
+#define GB 4                        // boards per workgroup
+#define BPOS 64                     // positions per board in the HBM layout
+#define SLAB_POS 258                // 3*64 + 48 + 2*9
+#define ROWB 272                    // LDS row stride in bytes: 256 + 16 (17 slots of 16 B, odd)
+#define NT 512
+
+// blob layout (bytes); must match alphazero_amd/net.py pack_c4_blob_128
+#define G_W 0                                        // bf16 [2 convs][9 taps][128 co][128 ci]
+#define G_STEM (G_W + 2 * 9 * CH * CH * 2)           // f32 [18][128]  k = tap*2 + plane
+#define G_BIAS (G_STEM + 18 * CH * 4)                // f32 [3][128]   stem, c1, c2
+#define G_HW (G_BIAS + 3 * CH * 4)                   // f32 [3][128]   1x1 heads: policy 0, 1, value
+#define G_HB (G_HW + 3 * CH * 4)                     // f32 [4]
+#define G_WP (G_HB + 16)                             // f32 [42][84]
+#define G_BP (G_WP + 42 * 84 * 4)                    // f32 [44]
+#define G_W1T (G_BP + 44 * 4)                        // f32 [42][256]
+#define G_B1 (G_W1T + 42 * 256 * 4)                  // f32 [256]
+#define G_W2 (G_B1 + 256 * 4)                        // f32 [256]
+#define G_B2 (G_W2 + 256 * 4)                        // f32 [4]
+#define G_BLOB_BYTES (G_B2 + 16)
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+__host__ __device__ static inline size_t act_positions(int n) { return 1 + (size_t)((n + GB - 1) / GB * GB) * BPOS + 16; }
+
+// ---- stem: 2 -> 128 channels straight from the bitboards (vector ALU, fp32 accumulate) ----------
+__global__ void __launch_bounds__(256) k_stem128(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ leaf_bb,
+                                                 int n, __bf16* __restrict__ out) {
+    __shared__ float w[18 * CH];
+    __shared__ float bias[CH];
+    for (int i = threadIdx.x; i < 18 * CH; i += 256) w[i] = reinterpret_cast<const float*>(blob + G_STEM)[i];
+    if (threadIdx.x < CH) bias[threadIdx.x] = reinterpret_cast<const float*>(blob + G_BIAS)[threadIdx.x];
+    __syncthreads();
+    // thread = (board, position o, 16-channel group)
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const int cg = (int)(t & 7);
+    const long bo = t >> 3;
+    const int o = (int)(bo % 48);
+    const long b = bo / 48;
+    if (b >= n) return;
+    const int y = o >> 3, x = o & 7;
+    __bf16* dst = out + ((size_t)1 + b * BPOS + 8 + o) * CH + cg * 16;
+    if (x == 7) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) dst[c] = (__bf16)0.0f;
+        return;
+    }
+    const uint64_t bb0 = leaf_bb[2 * b] << 8, bb1 = leaf_bb[2 * b + 1] << 8;
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = bias[cg * 16 + c];
+    for (int tap = 0; tap < 9; ++tap) {
+        const int sh = (x + tap % 3) * 7 + (y + tap / 3);
+        if ((bb0 >> sh) & 1ull) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc[c] += w[(2 * tap) * CH + cg * 16 + c];
+        }
+        if ((bb1 >> sh) & 1ull) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc[c] += w[(2 * tap + 1) * CH + cg * 16 + c];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) dst[c] = (__bf16)fmaxf(acc[c], 0.0f);
+}
+
+// ---- 3x3 conv 128 -> 128 (+ bias, optional residual, ReLU) ---------------------------------------
+template <bool RES>
+__global__ void __launch_bounds__(NT, 2)
+k_conv128(const uint8_t* __restrict__ wts /* [9][128][128] bf16 */, const float* __restrict__ bias,
+          const __bf16* __restrict__ in, const __bf16* __restrict__ res, __bf16* __restrict__ out, int nboards) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t* xs = lds;                               // [SLAB_POS][ROWB]
+    uint8_t* ws = lds + SLAB_POS * ROWB;             // [2][128][ROWB]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, col = lane & 31;
+    const int wc = wave & 3, wp = wave >> 2;
+    const long b0 = (long)blockIdx.x * GB;
+    (void)nboards;
+
+    // stage the input slab: global positions [b0*64, b0*64 + 258), 16 pieces of 16 B per position
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(in + (size_t)b0 * BPOS * CH);
+        for (int i = tid; i < SLAB_POS * 16; i += NT) {
+            const int q = i >> 4, piece = i & 15;
+            *reinterpret_cast<uint4*>(xs + q * ROWB + piece * 16) = src[i];
+        }
+    }
+    // weights of tap 0: [128 co][128 ci] = 2048 pieces of 16 B
+    uint4 wreg[4];
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(wts);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = tid + j * NT;
+            *reinterpret_cast<uint4*>(ws + (i >> 4) * ROWB + (i & 15) * 16) = src[i];
+        }
+    }
+    __syncthreads();
+
+    // this wave's three position tiles
+    int q[3];
+    bool keep[3];
+    long gpos[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int R = (wp * 3 + t) * 32 + col;
+        const int bl = R / 48, o = R - bl * 48;
+        q[t] = bl * BPOS + 9 + o;
+        keep[t] = (o & 7) != 7;
+        gpos[t] = 1 + (b0 + bl) * BPOS + 8 + o;
+    }
+    f32x16 acc[3];
+    {
+        const float* bp = bias + 32 * wc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float bv = bp[(r & 3) + 8 * (r >> 2) + 4 * h];
+            acc[0][r] = bv; acc[1][r] = bv; acc[2][r] = bv;
+        }
+    }
+
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+        if (tap + 1 < 9) {                      // next tap's weights travel to registers under this tap's MFMAs
+            const uint4* src = reinterpret_cast<const uint4*>(wts + (size_t)(tap + 1) * CH * CH * 2);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wreg[j] = src[tid + j * NT];
+        }
+        const uint8_t* wb = ws + (tap & 1) * CH * ROWB + (32 * wc + col) * ROWB + h * 16;
+        const int d = ((tap / 3 - 1) * 8 + (tap % 3 - 1)) * ROWB + h * 16;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(wb + s * 32);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(xs + q[t] * ROWB + d + s * 32);
+                acc[t] = MFMA(a, b, acc[t]);
+            }
+        }
+        if (tap + 1 < 9) {
+            uint8_t* wn = ws + ((tap + 1) & 1) * CH * ROWB;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = tid + j * NT;
+                *reinterpret_cast<uint4*>(wn + (i >> 4) * ROWB + (i & 15) * 16) = wreg[j];
+            }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: register r = channel 32*wc + (r&3) + 8*(r>>2) + 4*h of position col
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const size_t off = (size_t)gpos[t] * CH + 32 * wc + 8 * g + 4 * h;
+            float x0 = acc[t][4 * g], x1 = acc[t][4 * g + 1], x2 = acc[t][4 * g + 2], x3 = acc[t][4 * g + 3];
+            if (RES) {
+                const uint2 r = *reinterpret_cast<const uint2*>(res + off);
+                x0 += __uint_as_float(r.x << 16); x1 += __uint_as_float(r.x & 0xFFFF0000u);
+                x2 += __uint_as_float(r.y << 16); x3 += __uint_as_float(r.y & 0xFFFF0000u);
+            }
+            bf16x4 y;
+            y[0] = (__bf16)fmaxf(x0, 0.0f); y[1] = (__bf16)fmaxf(x1, 0.0f);
+            y[2] = (__bf16)fmaxf(x2, 0.0f); y[3] = (__bf16)fmaxf(x3, 0.0f);
+            if (!keep[t]) { y[0] = (__bf16)0.0f; y[1] = y[0]; y[2] = y[0]; y[3] = y[0]; }
+            *reinterpret_cast<bf16x4*>(out + off) = y;
+        }
+    }
+}
+
+// ---- heads: 1x1 convs, FCs, landing-cell gather, soft-max (vector ALU, fp32) ---------------------
+#define HB_ 8
+__global__ void __launch_bounds__(256) k_heads128(const uint8_t* __restrict__ blob, const __bf16* __restrict__ act,
+                                                  const uint64_t* __restrict__ leaf_bb, int n, float* __restrict__ p_out,
+                                                  float* __restrict__ v_out) {
+    __shared__ float hpv[HB_ * 3 * 42];
+    __shared__ float hid[256 * HB_];
+    const int tid = threadIdx.x;
+    const long board0 = (long)blockIdx.x * HB_;
+    const float* hw = reinterpret_cast<const float*>(blob + G_HW);
+    const float* hb = reinterpret_cast<const float*>(blob + G_HB);
+    // (board, cell) pairs, the three 128-long dot products of each
+    for (int i = tid; i < HB_ * 42; i += 256) {
+        const int b = i / 42, cell = i - b * 42;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        if (board0 + b < n) {
+            const __bf16* xs = act + ((size_t)1 + (board0 + b) * BPOS + 8 + (cell / 7) * 8 + cell % 7) * CH;
+            for (int c = 0; c < CH; c += 8) {
+                const bf16x8 xv = *reinterpret_cast<const bf16x8*>(xs + c);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xf = (float)xv[j];
+                    a0 = fmaf(hw[c + j], xf, a0);
+                    a1 = fmaf(hw[CH + c + j], xf, a1);
+                    a2 = fmaf(hw[2 * CH + c + j], xf, a2);
+                }
+            }
+        }
+        hpv[(b * 3 + 0) * 42 + cell] = fmaxf(a0 + hb[0], 0.0f);
+        hpv[(b * 3 + 1) * 42 + cell] = fmaxf(a1 + hb[1], 0.0f);
+        hpv[(b * 3 + 2) * 42 + cell] = fmaxf(a2 + hb[2], 0.0f);
+    }
+    __syncthreads();
+    {
+        const float* w1t = reinterpret_cast<const float*>(blob + G_W1T);
+        float a[HB_];
+#pragma unroll
+        for (int b = 0; b < HB_; ++b) a[b] = 0.0f;
+        for (int i = 0; i < 42; ++i) {
+            const float wv = w1t[i * 256 + tid];
+#pragma unroll
+            for (int b = 0; b < HB_; ++b) a[b] = fmaf(wv, hpv[(b * 3 + 2) * 42 + i], a[b]);
+        }
+        const float b1 = reinterpret_cast<const float*>(blob + G_B1)[tid];
+        const float w2v = reinterpret_cast<const float*>(blob + G_W2)[tid];
+#pragma unroll
+        for (int b = 0; b < HB_; ++b) hid[tid * HB_ + b] = fmaxf(a[b] + b1, 0.0f) * w2v;
+    }
+    __syncthreads();
+    if (tid < HB_ * 8) {
+        const int b = tid >> 3, c = tid & 7;
+        const long gidx = board0 + b;
+        uint64_t occ = 0;
+        if (gidx < n) occ = leaf_bb[2 * gidx] | leaf_bb[2 * gidx + 1];
+        const int height = c < 7 ? __popcll((occ >> (7 * c)) & 0x3Full) : 6;
+        const bool legal = c < 7 && height < 6;
+        float logit = -INFINITY;
+        if (legal) {
+            const int cell = height * 7 + c;
+            const float* wrow = reinterpret_cast<const float*>(blob + G_WP) + cell * 84;
+            float s = reinterpret_cast<const float*>(blob + G_BP)[cell];
+            for (int j = 0; j < 84; ++j) s = fmaf(wrow[j], hpv[(b * 3 + j / 42) * 42 + j % 42], s);
+            logit = s;
+        }
+        float m = logit;
+        m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4));
+        const float e = legal ? __expf(logit - m) : 0.0f;
+        float sum = e;
+        sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
+        if (c < 7 && gidx < n) p_out[(size_t)gidx * 7 + c] = legal ? e / sum : 0.0f;
+    } else if (tid >= 128 && tid < 128 + HB_) {
+        const int b = tid - 128;
+        const long gidx = board0 + b;
+        float s = 0.0f;
+        for (int u = 0; u < 256; ++u) s += hid[u * HB_ + b];
+        if (gidx < n) v_out[gidx] = tanhf(s + reinterpret_cast<const float*>(blob + G_B2)[0]);
+    }
+}
+
+extern "C" {
+
+int az_c4net128_blob_bytes(void) { return G_BLOB_BYTES; }
+
+// three activation tensors; the caller zero-fills the workspace once (zero rows are never written)
+long az_c4net128_workspace_bytes(int32_t n) { return n < 0 ? -1 : (long)(3 * act_positions(n) * CH * 2); }
+
+int az_c4net128_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uint64_t* leaf_bb, int32_t n,
+                             void* workspace, float* p, float* v, void* stream) {
+    if (n < 0 || num_blocks < 0 || (n && (!blob || !leaf_bb || !workspace || !p || !v))) return -1;
+    if (n == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t tsz = act_positions(n) * CH;                    // elements per tensor
+    __bf16* t0 = reinterpret_cast<__bf16*>(workspace);
+    __bf16* t1 = t0 + tsz;
+    const int lds = SLAB_POS * ROWB + 2 * CH * ROWB;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv128<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv128<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return -2;
+        attr_set = true;
+    }
+    const int ngroups = (n + GB - 1) / GB;
+    const long stem_threads = (long)n * 48 * 8;
+    hipLaunchKernelGGL(k_stem128, dim3((unsigned)((stem_threads + 255) / 256)), dim3(256), 0, st, blob, leaf_bb, (int)n, t0);
+    const float* bias = reinterpret_cast<const float*>(blob + G_BIAS);
+    for (int blk = 0; blk < num_blocks; ++blk) {
+        hipLaunchKernelGGL((k_conv128<false>), dim3(ngroups), dim3(NT), lds, st, blob + G_W, bias + CH, t0,
+                           (const __bf16*)nullptr, t1, (int)n);
+        hipLaunchKernelGGL((k_conv128<true>), dim3(ngroups), dim3(NT), lds, st, blob + G_W + (size_t)9 * CH * CH * 2,
+                           bias + 2 * CH, t1, t0, t0, (int)n);
+    }
+    hipLaunchKernelGGL(k_heads128, dim3((n + HB_ - 1) / HB_), dim3(256), 0, st, blob, t0, leaf_bb, (int)n, p, v);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+}  // extern "C"

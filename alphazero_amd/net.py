@@ -203,3 +203,59 @@ class FusedC4NetF32:
         check(self.lib.az_c4net_f32_forward(ptr(self.blob), self.num_blocks, ptr(leaf_bb), n,
                                             ptr(self._p), ptr(self._v), st))
         return self._p, self._v
+
+
+def pack_c4_blob_128(model):
+    """AlphaZeroC4 with 128 trunk channels -> uint8 blob in the layout of csrc/az_net128.hip."""
+    if model.block_channels != 128 or tuple(model.shape_in) != (2, 6, 7):
+        raise ValueError('az_net128 is for Connect Four nets with 128 trunk channels')
+    dev = model._cbr[0].weight.device
+    with torch.no_grad():
+        w, b0 = _fold_bn(model._cbr[0].weight, model._cbr[1])
+        stem = w.permute(2, 3, 1, 0).reshape(18, 128)                      # k = tap*2 + plane
+        blk = model._tower[0]
+        w1, b1 = _fold_bn(blk._c1.weight, blk._bn1)
+        w2, b2 = _fold_bn(blk._c2.weight, blk._bn2)
+        wts = torch.stack([w1.permute(2, 3, 0, 1).reshape(9, 128, 128),     # [tap][co][ci]
+                           w2.permute(2, 3, 0, 1).reshape(9, 128, 128)])
+        ph, vh = model._policy_head, model._value_head
+        wpol, bpol = _fold_bn(ph._cbr[0].weight, ph._cbr[1], ph._cbr[0].bias)
+        wval, bval = _fold_bn(vh._cbr[0].weight, vh._cbr[1])
+        hw = torch.cat([wpol[:, :, 0, 0], wval[:, :, 0, 0]])               # [3][128]
+        z = lambda k: torch.zeros(k, dtype=torch.float64, device=dev)
+        f32 = [stem, torch.stack([b0, b1, b2]), hw, torch.cat([bpol[:2], bval[:1], z(1)]),
+               ph._fc.weight.double(), torch.cat([ph._fc.bias.double(), z(2)]),
+               vh._fc[0].weight.double().t().contiguous(), vh._fc[0].bias.double(), vh._fc[2].weight.double(),
+               torch.cat([vh._fc[2].bias.double().reshape(1), z(3)])]
+        blob = torch.cat([wts.float().to(torch.bfloat16).contiguous().view(torch.uint8).reshape(-1)] +
+                         [t.reshape(-1).float().contiguous().view(torch.uint8) for t in f32])
+    assert blob.numel() == _lib.load().az_c4net128_blob_bytes(), blob.numel()
+    return blob
+
+
+class C4Net128:
+    """Leaf evaluator for 128-channel Connect Four nets: net(leaf_bb, leaf_info) -> (p, v)."""
+
+    def __init__(self, model, device=None, max_leaves=16384):
+        self.lib = _lib.load()
+        self.device = torch.device(device if device is not None else next(model.parameters()).device)
+        self.num_blocks = model.num_blocks
+        self.blob = pack_c4_blob_128(model).to(self.device)
+        self.max_leaves = max_leaves
+        nbytes = self.lib.az_c4net128_workspace_bytes(max_leaves)
+        self.workspace = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)   # zero rows stay zero
+        self._p = self._v = None
+
+    def load_module(self, model):
+        self.blob.copy_(pack_c4_blob_128(model))
+
+    def __call__(self, leaf_bb, leaf_info=None):
+        n = leaf_bb.shape[0]
+        assert n <= self.max_leaves
+        if self._p is None or self._p.shape[0] != n:
+            self._p = torch.empty(n, 7, dtype=torch.float32, device=self.device)
+            self._v = torch.empty(n, dtype=torch.float32, device=self.device)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(self.lib.az_c4net128_bf16_forward(ptr(self.blob), self.num_blocks, ptr(leaf_bb), n,
+                                                ptr(self.workspace), ptr(self._p), ptr(self._v), st))
+        return self._p, self._v

@@ -116,3 +116,34 @@ def test_fused_fp32_forward_matches_torch_fp32(blocks, ch, n):
     assert torch.allclose(p, pref, rtol=1e-5, atol=1e-6), (p - pref).abs().max().item()
     assert torch.allclose(v, vref.reshape(-1), rtol=1e-5, atol=1e-6), (v - vref.reshape(-1)).abs().max().item()
     print('fp32 max |dp|', (p - pref).abs().max().item(), 'max |dv|', (v - vref.reshape(-1)).abs().max().item())
+
+
+@pytest.mark.parametrize('blocks,n', [(2, 301), (10, 130)])
+def test_trunk128_bf16_matches_torch_fp32(blocks, n):
+    """128-channel trunk (the 10x128 leaf-eval configuration) on bf16 MFMA vs the fp32 torch net."""
+    from alphazero_amd import engine as E
+    from alphazero_amd.models import AlphaZeroC4
+    from alphazero_amd.net import C4Net128
+    torch.manual_seed(40 + blocks)
+    model = AlphaZeroC4(blocks, 128).eval()
+    _randomize_bn(model, 8)
+    with torch.no_grad():               # keep the shared-block tower from amplifying activations
+        model._tower[0]._bn2.weight.mul_(0.5)
+    hists = _random_positions(n, 13)
+    bb, nm = E.positions_from_history(1, hists)
+    net = C4Net128(model, 'cuda', max_leaves=512)
+    for rep in range(2):                # second call reuses the workspace
+        p, v = net(bb)
+    p, v = p.cpu(), v.cpu()
+    x, valid = E.render(1, bb)
+    with torch.no_grad():
+        logits, vref = model(x.cpu(), valid.cpu())
+    valid = valid.cpu()
+    pref = torch.zeros_like(logits)
+    for i in range(n):
+        pref[i, valid[i]] = torch.softmax(logits[i, valid[i]], 0)
+    dp, dv = (p - pref).abs().max().item(), (v - vref.reshape(-1)).abs().max().item()
+    print('128ch blocks', blocks, 'max |dp|', dp, 'max |dv|', dv)
+    assert torch.all(p[~valid] == 0)
+    # bf16 activations and weights through 2*blocks+1 convs of K = 1152: 2e-2 absolute on p, v
+    assert dp < 2e-2 and dv < 2e-2
