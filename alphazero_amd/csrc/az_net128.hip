@@ -8,10 +8,8 @@
 //
 // Activation tensor: [1 guard][board][8 rows x 8 cols][128 ch] bf16, row 0 and row 7 of every
 // board and column 7 of every row are zero, so a 3x3 tap is a constant position offset (the same
-// trick as the LDS image of az_net.hip).  A workgroup (8 waves) computes 4 boards x 48 positions
-// x 128 output channels: the input slab (258 positions incl. halo) is staged in LDS once, the
-// weights stream through LDS one tap (128x128) at a time, double buffered, and every wave owns a
-// 32-channel x 96-position output block (3 accumulators), so one A fragment feeds 3 MFMAs.
+// trick as the LDS image of az_net.hip).  A workgroup computes 4 boards x 48 positions x 128 output
+// channels from an input slab (258 positions incl. halo) staged in LDS once; see k_conv128.
 // D[co][pos] orientation puts 4 consecutive channels of one position in 4 registers: the epilogue
 // (bias, residual, ReLU, bf16) stores 8 bytes per lane.
 #include <hip/hip_runtime.h>
@@ -28,10 +26,10 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define BPOS 64                     // positions per board in the HBM layout
 #define SLAB_POS 258                // 3*64 + 48 + 2*9
 #define ROWB 272                    // LDS row stride in bytes: 256 + 16 (17 slots of 16 B, odd)
-#define NT 512
+#define NT 256
 
 // blob layout (bytes); must match alphazero_amd/net.py pack_c4_blob_128
-#define G_W 0                                        // bf16 [2 convs][9 taps][128 co][128 ci]
+#define G_W 0                                        // bf16 [2 convs][9 taps][4 co tiles][8 k-steps][64 lanes][8]
 #define G_STEM (G_W + 2 * 9 * CH * CH * 2)           // f32 [18][128]  k = tap*2 + plane
 #define G_BIAS (G_STEM + 18 * CH * 4)                // f32 [3][128]   stem, c1, c2
 #define G_HW (G_BIAS + 3 * CH * 4)                   // f32 [3][128]   1x1 heads: policy 0, 1, value
@@ -90,96 +88,116 @@ __global__ void __launch_bounds__(256) k_stem128(const uint8_t* __restrict__ blo
 }
 
 // ---- 3x3 conv 128 -> 128 (+ bias, optional residual, ReLU) ---------------------------------------
+// Workgroup = 4 waves, 4 boards; two workgroups share a CU (2 x 70 KB of LDS), so one group's slab
+// load and epilogue run under the other's MFMAs.  Wave (wc, wp) owns channels [64 wc, 64 wc + 64) of
+// positions [96 wp, 96 wp + 96): 2 x 3 accumulators, so each activation fragment read from LDS feeds
+// two MFMAs.  Weights never touch LDS: they are stored in fragment order
+// [tap][32-channel tile][k-step][lane][8 bf16], every lane reads its 16 bytes straight from L2, half
+// a tap (4 k-steps x 2 tiles) ahead of use, into one of two register buffers.
+__device__ __forceinline__ void load_wfrag(uint4 (&buf)[8], const uint4* __restrict__ wq, int tap, int wc, int hf, int lane) {
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            buf[c2 * 4 + s] = wq[(((tap * 4 + 2 * wc + c2) * 8) + 4 * hf + s) * 64 + lane];
+}
+
+__device__ __forceinline__ void mma_half(f32x16 (&acc)[2][3], const uint4 (&buf)[8], const uint8_t* xs, const int (&qoff)[3],
+                                         int d, int hf) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int kb = d + (4 * hf + s) * 32;
+        bf16x8 a0, a1;
+        __builtin_memcpy(&a0, &buf[s], 16);
+        __builtin_memcpy(&a1, &buf[4 + s], 16);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(xs + qoff[t] + kb);
+            acc[0][t] = MFMA(a0, b, acc[0][t]);
+            acc[1][t] = MFMA(a1, b, acc[1][t]);
+        }
+    }
+}
+
 template <bool RES>
 __global__ void __launch_bounds__(NT, 2)
-k_conv128(const uint8_t* __restrict__ wts /* [9][128][128] bf16 */, const float* __restrict__ bias,
+k_conv128(const uint8_t* __restrict__ wts /* fragment order, one conv */, const float* __restrict__ bias,
           const __bf16* __restrict__ in, const __bf16* __restrict__ res, __bf16* __restrict__ out, int nboards) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t* xs = lds;                               // [SLAB_POS][ROWB]
-    uint8_t* ws = lds + SLAB_POS * ROWB;             // [2][128][ROWB]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, col = lane & 31;
-    const int wc = wave & 3, wp = wave >> 2;
+    const int wc = wave & 1, wp = wave >> 1;
     const long b0 = (long)blockIdx.x * GB;
     (void)nboards;
+    const uint4* wq = reinterpret_cast<const uint4*>(wts);
 
-    // stage the input slab: global positions [b0*64, b0*64 + 258), 16 pieces of 16 B per position
+    uint4 bufa[8], bufb[8];
+    load_wfrag(bufa, wq, 0, wc, 0, lane);
+
+    // stage the input slab: global positions [b0*64, b0*64 + 258), 16 pieces of 16 B per position;
+    // loads go out in batches so their latencies overlap
     {
         const uint4* src = reinterpret_cast<const uint4*>(in + (size_t)b0 * BPOS * CH);
-        for (int i = tid; i < SLAB_POS * 16; i += NT) {
-            const int q = i >> 4, piece = i & 15;
-            *reinterpret_cast<uint4*>(xs + q * ROWB + piece * 16) = src[i];
-        }
-    }
-    // weights of tap 0: [128 co][128 ci] = 2048 pieces of 16 B
-    uint4 wreg[4];
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(wts);
+        constexpr int TOTAL = SLAB_POS * 16;
+        constexpr int BATCH = 9;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = tid + j * NT;
-            *reinterpret_cast<uint4*>(ws + (i >> 4) * ROWB + (i & 15) * 16) = src[i];
+        for (int base = 0; base < TOTAL; base += BATCH * NT) {
+            uint4 tmp[BATCH];
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j) {
+                const int i = base + tid + j * NT;
+                tmp[j] = i < TOTAL ? src[i] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j) {
+                const int i = base + tid + j * NT;
+                if (i < TOTAL) *reinterpret_cast<uint4*>(xs + (i >> 4) * ROWB + (i & 15) * 16) = tmp[j];
+            }
         }
     }
     __syncthreads();
 
     // this wave's three position tiles
-    int q[3];
+    int qoff[3];
     bool keep[3];
     long gpos[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         const int R = (wp * 3 + t) * 32 + col;
         const int bl = R / 48, o = R - bl * 48;
-        q[t] = bl * BPOS + 9 + o;
+        qoff[t] = (bl * BPOS + 9 + o) * ROWB + h * 16;
         keep[t] = (o & 7) != 7;
         gpos[t] = 1 + (b0 + bl) * BPOS + 8 + o;
     }
-    f32x16 acc[3];
-    {
-        const float* bp = bias + 32 * wc;
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2) {
+        const float* bp = bias + 64 * wc + 32 * c2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float bv = bp[(r & 3) + 8 * (r >> 2) + 4 * h];
-            acc[0][r] = bv; acc[1][r] = bv; acc[2][r] = bv;
+            acc[c2][0][r] = bv; acc[c2][1][r] = bv; acc[c2][2][r] = bv;
         }
     }
 
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
-        if (tap + 1 < 9) {                      // next tap's weights travel to registers under this tap's MFMAs
-            const uint4* src = reinterpret_cast<const uint4*>(wts + (size_t)(tap + 1) * CH * CH * 2);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) wreg[j] = src[tid + j * NT];
-        }
-        const uint8_t* wb = ws + (tap & 1) * CH * ROWB + (32 * wc + col) * ROWB + h * 16;
-        const int d = ((tap / 3 - 1) * 8 + (tap % 3 - 1)) * ROWB + h * 16;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(wb + s * 32);
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const bf16x8 b = *reinterpret_cast<const bf16x8*>(xs + q[t] * ROWB + d + s * 32);
-                acc[t] = MFMA(a, b, acc[t]);
-            }
-        }
-        if (tap + 1 < 9) {
-            uint8_t* wn = ws + ((tap + 1) & 1) * CH * ROWB;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int i = tid + j * NT;
-                *reinterpret_cast<uint4*>(wn + (i >> 4) * ROWB + (i & 15) * 16) = wreg[j];
-            }
-        }
-        __syncthreads();
+        const int d = ((tap / 3 - 1) * 8 + (tap % 3 - 1)) * ROWB;
+        load_wfrag(bufb, wq, tap, wc, 1, lane);
+        mma_half(acc, bufa, xs, qoff, d, 0);
+        if (tap + 1 < 9) load_wfrag(bufa, wq, tap + 1, wc, 0, lane);
+        mma_half(acc, bufb, xs, qoff, d, 1);
     }
 
-    // epilogue: register r = channel 32*wc + (r&3) + 8*(r>>2) + 4*h of position col
+    // epilogue: register r = channel (r&3) + 8*(r>>2) + 4*h of the tile, position col
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const size_t off = (size_t)gpos[t] * CH + 32 * wc + 8 * g + 4 * h;
-            float x0 = acc[t][4 * g], x1 = acc[t][4 * g + 1], x2 = acc[t][4 * g + 2], x3 = acc[t][4 * g + 3];
+            const size_t off = (size_t)gpos[t] * CH + 64 * wc + 32 * c2 + 8 * g + 4 * h;
+            float x0 = acc[c2][t][4 * g], x1 = acc[c2][t][4 * g + 1], x2 = acc[c2][t][4 * g + 2], x3 = acc[c2][t][4 * g + 3];
             if (RES) {
                 const uint2 r = *reinterpret_cast<const uint2*>(res + off);
                 x0 += __uint_as_float(r.x << 16); x1 += __uint_as_float(r.x & 0xFFFF0000u);
@@ -288,7 +306,7 @@ int az_c4net128_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uint
     const size_t tsz = act_positions(n) * CH;                    // elements per tensor
     __bf16* t0 = reinterpret_cast<__bf16*>(workspace);
     __bf16* t1 = t0 + tsz;
-    const int lds = SLAB_POS * ROWB + 2 * CH * ROWB;
+    const int lds = SLAB_POS * ROWB;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv128<false>),

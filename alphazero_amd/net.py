@@ -227,6 +227,9 @@ def pack_c4_blob_128(model):
                ph._fc.weight.double(), torch.cat([ph._fc.bias.double(), z(2)]),
                vh._fc[0].weight.double().t().contiguous(), vh._fc[0].bias.double(), vh._fc[2].weight.double(),
                torch.cat([vh._fc[2].bias.double().reshape(1), z(3)])]
+        # MFMA A-fragment order: [conv][tap][co tile][k-step][lane = h*32 + col][8], element j of a
+        # lane is W[co = 32*tile + col][ci = 16*step + 8*h + j]
+        wts = wts.reshape(2, 9, 4, 32, 8, 2, 8).permute(0, 1, 2, 4, 5, 3, 6)
         blob = torch.cat([wts.float().to(torch.bfloat16).contiguous().view(torch.uint8).reshape(-1)] +
                          [t.reshape(-1).float().contiguous().view(torch.uint8) for t in f32])
     assert blob.numel() == _lib.load().az_c4net128_blob_bytes(), blob.numel()
