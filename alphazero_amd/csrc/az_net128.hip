@@ -1,17 +1,17 @@
-// az_net128.hip -- 128-channel Connect Four trunk on bf16 MFMA (gfx950), layer by layer.
+// az_net128.hip -- 128-channel Connect Four network on bf16 MFMA (gfx950).
 //
 // The 10x128 network (alphazero/models.py:70-87 with block_channels = 128) has 295 KB of bf16
 // weights per 3x3 conv: they fit neither registers nor LDS, so unlike the 32-channel kernel
-// (az_net.hip) the trunk runs as one launch per conv with bf16 activations in HBM.  Per conv the
-// algorithmic work is 2*9*128*128*42 = 12.4 MFLOP per leaf against 2*56*256 B of activation
-// traffic, i.e. ~430 FLOP/B: matrix-core bound.
+// (az_net.hip) the weights stream from L2 while the activations of four boards stay in LDS for the
+// whole residual tower.  Per conv the algorithmic work is 2*9*128*128*42 = 12.4 MFLOP per leaf.
 //
+// Three launches: stem (bitboards -> bf16 activations in HBM), tower (in place), heads.
 // Activation tensor: [1 guard][board][8 rows x 8 cols][128 ch] bf16, row 0 and row 7 of every
 // board and column 7 of every row are zero, so a 3x3 tap is a constant position offset (the same
-// trick as the LDS image of az_net.hip).  A workgroup computes 4 boards x 48 positions x 128 output
-// channels from an input slab (258 positions incl. halo) staged in LDS once; see k_conv128.
+// trick as the LDS image of az_net.hip) and a workgroup's slab of 4 boards plus halo is one
+// contiguous range of 258 positions.
 // D[co][pos] orientation puts 4 consecutive channels of one position in 4 registers: the epilogue
-// (bias, residual, ReLU, bf16) stores 8 bytes per lane.
+// (bias, residual, ReLU, bf16) moves 8 bytes per lane.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -26,7 +26,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define BPOS 64                     // positions per board in the HBM layout
 #define SLAB_POS 258                // 3*64 + 48 + 2*9
 #define ROWB 272                    // LDS row stride in bytes: 256 + 16 (17 slots of 16 B, odd)
-#define NT 256
+#define NT 512
 
 // blob layout (bytes); must match alphazero_amd/net.py pack_c4_blob_128
 #define G_W 0                                        // bf16 [2 convs][9 taps][4 co tiles][8 k-steps][64 lanes][8]
@@ -87,119 +87,54 @@ __global__ void __launch_bounds__(256) k_stem128(const uint8_t* __restrict__ blo
     for (int c = 0; c < 16; ++c) dst[c] = (__bf16)fmaxf(acc[c], 0.0f);
 }
 
-// ---- 3x3 conv 128 -> 128 (+ bias, optional residual, ReLU) ---------------------------------------
-// Workgroup = 4 waves, 4 boards; two workgroups share a CU (2 x 70 KB of LDS), so one group's slab
-// load and epilogue run under the other's MFMAs.  Wave (wc, wp) owns channels [64 wc, 64 wc + 64) of
-// positions [96 wp, 96 wp + 96): 2 x 3 accumulators, so each activation fragment read from LDS feeds
-// two MFMAs.  Weights never touch LDS: they are stored in fragment order
-// [tap][32-channel tile][k-step][lane][8 bf16], every lane reads its 16 bytes straight from L2, half
-// a tap (4 k-steps x 2 tiles) ahead of use, into one of two register buffers.
-__device__ __forceinline__ void load_wfrag(uint4 (&buf)[8], const uint4* __restrict__ wq, int tap, int wc, int hf, int lane) {
+// ---- residual tower: 2 * num_blocks 3x3 convs 128 -> 128, activations resident in LDS ----------
+// Workgroup = 8 waves, 4 boards.  Two activation slabs live in LDS for the whole tower: the first
+// conv of a block reads slab X and writes slab Y, the second reads Y, adds the block input (still in
+// X) and overwrites X in place -- HBM sees one read and one write of the activations per tower, not
+// per conv.  Wave (wc, wp) owns channels [32 wc, 32 wc + 32) of positions [96 wp, 96 wp + 96): three
+// accumulators fed by one weight fragment.  Weights never touch LDS: they are stored in fragment
+// order [conv][tap][32-channel tile][k-step][lane][8 bf16] and every lane reads its 16 bytes
+// straight from L2 one tap ahead of use, alternating between two register buffers; the prefetch
+// runs across conv boundaries, so the only bubble per conv is the epilogue and its barrier.
+#define CONV_BYTES (9 * CH * CH * 2)
+#define SLAB_BYTES (SLAB_POS * ROWB)
+
+__device__ __forceinline__ void load_wfrag(uint4 (&buf)[8], const uint8_t* __restrict__ wts, int g, int wc, int lane) {
+    const int conv = (g / 9) & 1, tap = g % 9;
+    const uint4* wq = reinterpret_cast<const uint4*>(wts + (size_t)conv * CONV_BYTES) + ((tap * 4 + wc) * 8) * 64 + lane;
 #pragma unroll
-    for (int c2 = 0; c2 < 2; ++c2)
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-            buf[c2 * 4 + s] = wq[(((tap * 4 + 2 * wc + c2) * 8) + 4 * hf + s) * 64 + lane];
+    for (int s = 0; s < 8; ++s) buf[s] = wq[s * 64];
 }
 
-__device__ __forceinline__ void mma_half(f32x16 (&acc)[2][3], const uint4 (&buf)[8], const uint8_t* xs, const int (&qoff)[3],
-                                         int d, int hf) {
+__device__ __forceinline__ void tower_tap(f32x16 (&acc)[3], const uint4 (&cur)[8], uint4 (&nxt)[8],
+                                          const uint8_t* __restrict__ wts, const float* __restrict__ bias, uint8_t* lds,
+                                          const int (&qrow)[3], const bool (&keep)[3], int g, int total, int wc, int h,
+                                          int lane) {
+    const int conv = g / 9, tap = g - conv * 9;
+    if (g + 1 < total) load_wfrag(nxt, wts, g + 1, wc, lane);
+    const uint8_t* src = lds + (conv & 1) * SLAB_BYTES + ((tap / 3 - 1) * 8 + (tap % 3 - 1)) * ROWB + h * 16;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int kb = d + (4 * hf + s) * 32;
-        bf16x8 a0, a1;
-        __builtin_memcpy(&a0, &buf[s], 16);
-        __builtin_memcpy(&a1, &buf[4 + s], 16);
+    for (int s = 0; s < 8; ++s) {
+        bf16x8 a;
+        __builtin_memcpy(&a, &cur[s], 16);
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-            const bf16x8 b = *reinterpret_cast<const bf16x8*>(xs + qoff[t] + kb);
-            acc[0][t] = MFMA(a0, b, acc[0][t]);
-            acc[1][t] = MFMA(a1, b, acc[1][t]);
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(src + qrow[t] + s * 32);
+            acc[t] = MFMA(a, b, acc[t]);
         }
     }
-}
-
-template <bool RES>
-__global__ void __launch_bounds__(NT, 2)
-k_conv128(const uint8_t* __restrict__ wts /* fragment order, one conv */, const float* __restrict__ bias,
-          const __bf16* __restrict__ in, const __bf16* __restrict__ res, __bf16* __restrict__ out, int nboards) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    uint8_t* xs = lds;                               // [SLAB_POS][ROWB]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, col = lane & 31;
-    const int wc = wave & 1, wp = wave >> 1;
-    const long b0 = (long)blockIdx.x * GB;
-    (void)nboards;
-    const uint4* wq = reinterpret_cast<const uint4*>(wts);
-
-    uint4 bufa[8], bufb[8];
-    load_wfrag(bufa, wq, 0, wc, 0, lane);
-
-    // stage the input slab: global positions [b0*64, b0*64 + 258), 16 pieces of 16 B per position;
-    // loads go out in batches so their latencies overlap
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(in + (size_t)b0 * BPOS * CH);
-        constexpr int TOTAL = SLAB_POS * 16;
-        constexpr int BATCH = 9;
-#pragma unroll
-        for (int base = 0; base < TOTAL; base += BATCH * NT) {
-            uint4 tmp[BATCH];
-#pragma unroll
-            for (int j = 0; j < BATCH; ++j) {
-                const int i = base + tid + j * NT;
-                tmp[j] = i < TOTAL ? src[i] : make_uint4(0, 0, 0, 0);
-            }
-#pragma unroll
-            for (int j = 0; j < BATCH; ++j) {
-                const int i = base + tid + j * NT;
-                if (i < TOTAL) *reinterpret_cast<uint4*>(xs + (i >> 4) * ROWB + (i & 15) * 16) = tmp[j];
-            }
-        }
-    }
-    __syncthreads();
-
-    // this wave's three position tiles
-    int qoff[3];
-    bool keep[3];
-    long gpos[3];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const int R = (wp * 3 + t) * 32 + col;
-        const int bl = R / 48, o = R - bl * 48;
-        qoff[t] = (bl * BPOS + 9 + o) * ROWB + h * 16;
-        keep[t] = (o & 7) != 7;
-        gpos[t] = 1 + (b0 + bl) * BPOS + 8 + o;
-    }
-    f32x16 acc[2][3];
-#pragma unroll
-    for (int c2 = 0; c2 < 2; ++c2) {
-        const float* bp = bias + 64 * wc + 32 * c2;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float bv = bp[(r & 3) + 8 * (r >> 2) + 4 * h];
-            acc[c2][0][r] = bv; acc[c2][1][r] = bv; acc[c2][2][r] = bv;
-        }
-    }
-
-#pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {
-        const int d = ((tap / 3 - 1) * 8 + (tap % 3 - 1)) * ROWB;
-        load_wfrag(bufb, wq, tap, wc, 1, lane);
-        mma_half(acc, bufa, xs, qoff, d, 0);
-        if (tap + 1 < 9) load_wfrag(bufa, wq, tap + 1, wc, 0, lane);
-        mma_half(acc, bufb, xs, qoff, d, 1);
-    }
-
-    // epilogue: register r = channel (r&3) + 8*(r>>2) + 4*h of the tile, position col
-#pragma unroll
-    for (int c2 = 0; c2 < 2; ++c2)
+    if (tap != 8) return;
+    // epilogue: register r = channel 32*wc + (r&3) + 8*(r>>2) + 4*h of position col
+    const bool second = conv & 1;
+    uint8_t* dst = lds + (second ? 0 : SLAB_BYTES) + (32 * wc + 4 * h) * 2;
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const size_t off = (size_t)gpos[t] * CH + 64 * wc + 32 * c2 + 8 * g + 4 * h;
-            float x0 = acc[c2][t][4 * g], x1 = acc[c2][t][4 * g + 1], x2 = acc[c2][t][4 * g + 2], x3 = acc[c2][t][4 * g + 3];
-            if (RES) {
-                const uint2 r = *reinterpret_cast<const uint2*>(res + off);
+        for (int gq = 0; gq < 4; ++gq) {
+            uint8_t* pos = dst + qrow[t] + 16 * gq;
+            float x0 = acc[t][4 * gq], x1 = acc[t][4 * gq + 1], x2 = acc[t][4 * gq + 2], x3 = acc[t][4 * gq + 3];
+            if (second) {
+                const uint2 r = *reinterpret_cast<const uint2*>(pos);
                 x0 += __uint_as_float(r.x << 16); x1 += __uint_as_float(r.x & 0xFFFF0000u);
                 x2 += __uint_as_float(r.y << 16); x3 += __uint_as_float(r.y & 0xFFFF0000u);
             }
@@ -207,9 +142,85 @@ k_conv128(const uint8_t* __restrict__ wts /* fragment order, one conv */, const 
             y[0] = (__bf16)fmaxf(x0, 0.0f); y[1] = (__bf16)fmaxf(x1, 0.0f);
             y[2] = (__bf16)fmaxf(x2, 0.0f); y[3] = (__bf16)fmaxf(x3, 0.0f);
             if (!keep[t]) { y[0] = (__bf16)0.0f; y[1] = y[0]; y[2] = y[0]; y[3] = y[0]; }
-            *reinterpret_cast<bf16x4*>(out + off) = y;
+            *reinterpret_cast<bf16x4*>(pos) = y;
         }
     }
+    // accumulators restart from the next conv's bias
+    const float* bp = bias + (second ? 1 : 2) * CH + 32 * wc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float bv = bp[(r & 3) + 8 * (r >> 2) + 4 * h];
+        acc[0][r] = bv; acc[1][r] = bv; acc[2][r] = bv;
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(NT, 2)
+k_tower128(const uint8_t* __restrict__ wts /* fragment order, two convs */, const float* __restrict__ bias /* [3][128] */,
+           __bf16* __restrict__ act, int num_blocks) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // [2][SLAB_POS][ROWB]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, col = lane & 31;
+    const int wc = wave & 3, wp = wave >> 2;
+    const long b0 = (long)blockIdx.x * GB;
+    const int total = 18 * num_blocks;
+
+    uint4 bufa[8], bufb[8];
+    load_wfrag(bufa, wts, 0, wc, lane);
+
+    // stage the input slab: global positions [b0*64, b0*64 + 258), 16 pieces of 16 B per position;
+    // every load is issued before the first LDS write so the latencies overlap.  The second slab
+    // starts as zeros (its halo and zero rows are never written afterwards).
+    uint4* gsl = reinterpret_cast<uint4*>(act + (size_t)b0 * BPOS * CH);
+    {
+        constexpr int TOTAL = SLAB_POS * 16;
+        constexpr int NLD = (TOTAL + NT - 1) / NT;
+        uint4 tmp[NLD];
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + j * NT;
+            tmp[j] = i < TOTAL ? gsl[i] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + j * NT;
+            if (i < TOTAL) {
+                const int o = (i >> 4) * ROWB + (i & 15) * 16;
+                *reinterpret_cast<uint4*>(lds + o) = tmp[j];
+                *reinterpret_cast<uint4*>(lds + SLAB_BYTES + o) = make_uint4(0, 0, 0, 0);
+            }
+        }
+    }
+
+    // this wave's three position tiles
+    int qrow[3];
+    bool keep[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int R = (wp * 3 + t) * 32 + col;
+        const int bl = R / 48, o = R - bl * 48;
+        qrow[t] = (bl * BPOS + 9 + o) * ROWB;
+        keep[t] = (o & 7) != 7;
+    }
+    f32x16 acc[3];
+    {
+        const float* bp = bias + CH + 32 * wc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float bv = bp[(r & 3) + 8 * (r >> 2) + 4 * h];
+            acc[0][r] = bv; acc[1][r] = bv; acc[2][r] = bv;
+        }
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int g = 0; g < total; g += 2) {
+        tower_tap(acc, bufa, bufb, wts, bias, lds, qrow, keep, g, total, wc, h, lane);
+        tower_tap(acc, bufb, bufa, wts, bias, lds, qrow, keep, g + 1, total, wc, h, lane);
+    }
+
+    // slab rows [9, 249) hold the four boards (the rows between boards are zero on both sides)
+    for (int i = 9 * 16 + tid; i < 249 * 16; i += NT)
+        gsl[i] = *reinterpret_cast<const uint4*>(lds + (i >> 4) * ROWB + (i & 15) * 16);
 }
 
 // ---- heads: 1x1 convs, FCs, landing-cell gather, soft-max (vector ALU, fp32) ---------------------
@@ -295,24 +306,20 @@ extern "C" {
 
 int az_c4net128_blob_bytes(void) { return G_BLOB_BYTES; }
 
-// three activation tensors; the caller zero-fills the workspace once (zero rows are never written)
-long az_c4net128_workspace_bytes(int32_t n) { return n < 0 ? -1 : (long)(3 * act_positions(n) * CH * 2); }
+// one activation tensor; the caller zero-fills the workspace once (zero rows are never written)
+long az_c4net128_workspace_bytes(int32_t n) { return n < 0 ? -1 : (long)(act_positions(n) * CH * 2); }
 
 int az_c4net128_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uint64_t* leaf_bb, int32_t n,
                              void* workspace, float* p, float* v, void* stream) {
     if (n < 0 || num_blocks < 0 || (n && (!blob || !leaf_bb || !workspace || !p || !v))) return -1;
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    const size_t tsz = act_positions(n) * CH;                    // elements per tensor
     __bf16* t0 = reinterpret_cast<__bf16*>(workspace);
-    __bf16* t1 = t0 + tsz;
-    const int lds = SLAB_POS * ROWB;
+    const int lds = 2 * SLAB_POS * ROWB;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv128<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv128<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower128), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                lds) != hipSuccess)
             return -2;
         attr_set = true;
     }
@@ -320,12 +327,8 @@ int az_c4net128_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uint
     const long stem_threads = (long)n * 48 * 8;
     hipLaunchKernelGGL(k_stem128, dim3((unsigned)((stem_threads + 255) / 256)), dim3(256), 0, st, blob, leaf_bb, (int)n, t0);
     const float* bias = reinterpret_cast<const float*>(blob + G_BIAS);
-    for (int blk = 0; blk < num_blocks; ++blk) {
-        hipLaunchKernelGGL((k_conv128<false>), dim3(ngroups), dim3(NT), lds, st, blob + G_W, bias + CH, t0,
-                           (const __bf16*)nullptr, t1, (int)n);
-        hipLaunchKernelGGL((k_conv128<true>), dim3(ngroups), dim3(NT), lds, st, blob + G_W + (size_t)9 * CH * CH * 2,
-                           bias + 2 * CH, t1, t0, t0, (int)n);
-    }
+    if (num_blocks > 0)
+        hipLaunchKernelGGL(k_tower128, dim3(ngroups), dim3(NT), lds, st, blob + G_W, bias, t0, (int)num_blocks);
     hipLaunchKernelGGL(k_heads128, dim3((n + HB_ - 1) / HB_), dim3(256), 0, st, blob, t0, leaf_bb, (int)n, p, v);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
