@@ -2,14 +2,14 @@
 //
 // The 10x128 network (alphazero/models.py:70-87 with block_channels = 128) has 295 KB of bf16
 // weights per 3x3 conv: they fit neither registers nor LDS, so unlike the 32-channel kernel
-// (az_net.hip) the weights stream from L2 while the activations of four boards stay in LDS for the
+// (az_net.hip) the weights stream from L2 while the activations of six boards stay in LDS for the
 // whole residual tower.  Per conv the algorithmic work is 2*9*128*128*42 = 12.4 MFLOP per leaf.
 //
 // Three launches: stem (bitboards -> bf16 activations in HBM), tower (in place), heads.
-// Activation tensor: [1 guard][board][8 rows x 8 cols][128 ch] bf16, row 0 and row 7 of every
-// board and column 7 of every row are zero, so a 3x3 tap is a constant position offset (the same
-// trick as the LDS image of az_net.hip) and a workgroup's slab of 4 boards plus halo is one
-// contiguous range of 258 positions.
+// Activation tensor: [board][42 cells, cell = 7*row + column][128 ch] bf16, dense.  The tower keeps
+// the same dense rows in LDS: 6 boards = 252 rows fill 8 MFMA tiles of 32 positions with 4 idle
+// rows, and a 3x3 tap that leaves the board reads a shared all-zero row instead (a per-lane select
+// from a 9-bit validity mask), so no matrix-core work is spent on padding.
 // D[co][pos] orientation puts 4 consecutive channels of one position in 4 registers: the epilogue
 // (bias, residual, ReLU, bf16) moves 8 bytes per lane.
 #include <hip/hip_runtime.h>
@@ -22,10 +22,12 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define CH 128
-#define GB 4                        // boards per workgroup
-#define BPOS 64                     // positions per board in the HBM layout
-#define SLAB_POS 258                // 3*64 + 48 + 2*9
+#define GB 6                        // boards per workgroup
+#define BPOS 42                     // positions per board
+#define NROW (GB * BPOS)            // 252 real rows per slab
+#define ZROW NROW                   // the all-zero row
 #define ROWB 272                    // LDS row stride in bytes: 256 + 16 (17 slots of 16 B, odd)
+#define SLAB_BYTES ((NROW + 1) * ROWB)
 #define NT 512
 
 // blob layout (bytes); must match alphazero_amd/net.py pack_c4_blob_128
@@ -44,7 +46,8 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
-__host__ __device__ static inline size_t act_positions(int n) { return 1 + (size_t)((n + GB - 1) / GB * GB) * BPOS + 16; }
+// rows of the activation tensor: whole workgroups of GB boards
+__host__ __device__ static inline size_t act_positions(int n) { return (size_t)((n + GB - 1) / GB * GB) * BPOS; }
 
 // ---- stem: 2 -> 128 channels straight from the bitboards (vector ALU, fp32 accumulate) ----------
 __global__ void __launch_bounds__(256) k_stem128(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ leaf_bb,
@@ -54,20 +57,23 @@ __global__ void __launch_bounds__(256) k_stem128(const uint8_t* __restrict__ blo
     for (int i = threadIdx.x; i < 18 * CH; i += 256) w[i] = reinterpret_cast<const float*>(blob + G_STEM)[i];
     if (threadIdx.x < CH) bias[threadIdx.x] = reinterpret_cast<const float*>(blob + G_BIAS)[threadIdx.x];
     __syncthreads();
-    // thread = (board, position o, 16-channel group)
+    // thread = (board, cell o, 16-channel group)
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     const int cg = (int)(t & 7);
     const long bo = t >> 3;
-    const int o = (int)(bo % 48);
-    const long b = bo / 48;
-    if (b >= n) return;
-    const int y = o >> 3, x = o & 7;
-    __bf16* dst = out + ((size_t)1 + b * BPOS + 8 + o) * CH + cg * 16;
-    if (x == 7) {
-#pragma unroll
-        for (int c = 0; c < 16; ++c) dst[c] = (__bf16)0.0f;
+    const int o = (int)(bo % BPOS);
+    const long b = bo / BPOS;
+    const int y = o / 7, x = o - 7 * y;
+    __bf16* dst = out + ((size_t)b * BPOS + o) * CH + cg * 16;
+    if (b >= n) {                         // boards that pad the last workgroup of the tower
+        if ((size_t)b * BPOS < act_positions(n)) {
+            reinterpret_cast<uint4*>(dst)[0] = make_uint4(0, 0, 0, 0);
+            reinterpret_cast<uint4*>(dst)[1] = make_uint4(0, 0, 0, 0);
+        }
         return;
     }
+    // bit of cell (row, column) is 7*column + row; shifted by 8 so that the 3x3 window never indexes
+    // below bit 0, and row 6 / column 7 land on bits that are always clear
     const uint64_t bb0 = leaf_bb[2 * b] << 8, bb1 = leaf_bb[2 * b + 1] << 8;
     float acc[16];
 #pragma unroll
@@ -83,21 +89,24 @@ __global__ void __launch_bounds__(256) k_stem128(const uint8_t* __restrict__ blo
             for (int c = 0; c < 16; ++c) acc[c] += w[(2 * tap + 1) * CH + cg * 16 + c];
         }
     }
+    bf16x8 lo, hi;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) dst[c] = (__bf16)fmaxf(acc[c], 0.0f);
+    for (int c = 0; c < 8; ++c) { lo[c] = (__bf16)fmaxf(acc[c], 0.0f); hi[c] = (__bf16)fmaxf(acc[8 + c], 0.0f); }
+    reinterpret_cast<bf16x8*>(dst)[0] = lo;
+    reinterpret_cast<bf16x8*>(dst)[1] = hi;
 }
 
 // ---- residual tower: 2 * num_blocks 3x3 convs 128 -> 128, activations resident in LDS ----------
-// Workgroup = 8 waves, 4 boards.  Two activation slabs live in LDS for the whole tower: the first
+// Workgroup = 8 waves, 6 boards.  Two activation slabs live in LDS for the whole tower: the first
 // conv of a block reads slab X and writes slab Y, the second reads Y, adds the block input (still in
 // X) and overwrites X in place -- HBM sees one read and one write of the activations per tower, not
-// per conv.  Wave (wc, wp) owns channels [32 wc, 32 wc + 32) of positions [96 wp, 96 wp + 96): three
+// per conv.  Wave (wc, wp) owns channels [32 wc, 32 wc + 32) of rows [128 wp, 128 wp + 128): four
 // accumulators fed by one weight fragment.  Weights never touch LDS: they are stored in fragment
 // order [conv][tap][32-channel tile][k-step][lane][8 bf16] and every lane reads its 16 bytes
 // straight from L2 one tap ahead of use, alternating between two register buffers; the prefetch
 // runs across conv boundaries, so the only bubble per conv is the epilogue and its barrier.
 #define CONV_BYTES (9 * CH * CH * 2)
-#define SLAB_BYTES (SLAB_POS * ROWB)
+#define NTILE 4
 
 __device__ __forceinline__ void load_wfrag(uint4 (&buf)[8], const uint8_t* __restrict__ wts, int g, int wc, int lane) {
     const int conv = (g / 9) & 1, tap = g % 9;
@@ -106,29 +115,34 @@ __device__ __forceinline__ void load_wfrag(uint4 (&buf)[8], const uint8_t* __res
     for (int s = 0; s < 8; ++s) buf[s] = wq[s * 64];
 }
 
-__device__ __forceinline__ void tower_tap(f32x16 (&acc)[3], const uint4 (&cur)[8], uint4 (&nxt)[8],
+__device__ __forceinline__ void tower_tap(f32x16 (&acc)[NTILE], const uint4 (&cur)[8], uint4 (&nxt)[8],
                                           const uint8_t* __restrict__ wts, const float* __restrict__ bias, uint8_t* lds,
-                                          const int (&qrow)[3], const bool (&keep)[3], int g, int total, int wc, int h,
-                                          int lane) {
+                                          const int (&qrow)[NTILE], const int (&vmask)[NTILE], int g, int total, int wc,
+                                          int h, int lane) {
     const int conv = g / 9, tap = g - conv * 9;
     if (g + 1 < total) load_wfrag(nxt, wts, g + 1, wc, lane);
-    const uint8_t* src = lds + (conv & 1) * SLAB_BYTES + ((tap / 3 - 1) * 8 + (tap % 3 - 1)) * ROWB + h * 16;
+    const uint8_t* src = lds + (conv & 1) * SLAB_BYTES + h * 16;
+    const int delta = ((tap / 3 - 1) * 7 + (tap % 3 - 1)) * ROWB;
+    int off[NTILE];
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) off[t] = ((vmask[t] >> tap) & 1) ? qrow[t] + delta : ZROW * ROWB;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         bf16x8 a;
         __builtin_memcpy(&a, &cur[s], 16);
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const bf16x8 b = *reinterpret_cast<const bf16x8*>(src + qrow[t] + s * 32);
+        for (int t = 0; t < NTILE; ++t) {
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(src + off[t] + s * 32);
             acc[t] = MFMA(a, b, acc[t]);
         }
     }
     if (tap != 8) return;
-    // epilogue: register r = channel 32*wc + (r&3) + 8*(r>>2) + 4*h of position col
+    // epilogue: register r = channel 32*wc + (r&3) + 8*(r>>2) + 4*h of the lane's row
     const bool second = conv & 1;
     uint8_t* dst = lds + (second ? 0 : SLAB_BYTES) + (32 * wc + 4 * h) * 2;
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
+    for (int t = 0; t < NTILE; ++t) {
+        if (vmask[t] == 0) continue;            // idle rows past the last board (the centre tap is valid on every real row)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             uint8_t* pos = dst + qrow[t] + 16 * gq;
@@ -141,7 +155,6 @@ __device__ __forceinline__ void tower_tap(f32x16 (&acc)[3], const uint4 (&cur)[8
             bf16x4 y;
             y[0] = (__bf16)fmaxf(x0, 0.0f); y[1] = (__bf16)fmaxf(x1, 0.0f);
             y[2] = (__bf16)fmaxf(x2, 0.0f); y[3] = (__bf16)fmaxf(x3, 0.0f);
-            if (!keep[t]) { y[0] = (__bf16)0.0f; y[1] = y[0]; y[2] = y[0]; y[3] = y[0]; }
             *reinterpret_cast<bf16x4*>(pos) = y;
         }
     }
@@ -150,7 +163,8 @@ __device__ __forceinline__ void tower_tap(f32x16 (&acc)[3], const uint4 (&cur)[8
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const float bv = bp[(r & 3) + 8 * (r >> 2) + 4 * h];
-        acc[0][r] = bv; acc[1][r] = bv; acc[2][r] = bv;
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) acc[t][r] = bv;
     }
     __syncthreads();
 }
@@ -158,21 +172,19 @@ __device__ __forceinline__ void tower_tap(f32x16 (&acc)[3], const uint4 (&cur)[8
 __global__ void __launch_bounds__(NT, 2)
 k_tower128(const uint8_t* __restrict__ wts /* fragment order, two convs */, const float* __restrict__ bias /* [3][128] */,
            __bf16* __restrict__ act, int num_blocks) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // [2][SLAB_POS][ROWB]
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // [2][NROW + 1][ROWB]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, col = lane & 31;
     const int wc = wave & 3, wp = wave >> 2;
-    const long b0 = (long)blockIdx.x * GB;
     const int total = 18 * num_blocks;
 
     uint4 bufa[8], bufb[8];
     load_wfrag(bufa, wts, 0, wc, lane);
 
-    // stage the input slab: global positions [b0*64, b0*64 + 258), 16 pieces of 16 B per position;
-    // every load is issued before the first LDS write so the latencies overlap.  The second slab
-    // starts as zeros (its halo and zero rows are never written afterwards).
-    uint4* gsl = reinterpret_cast<uint4*>(act + (size_t)b0 * BPOS * CH);
+    // stage the six boards: 252 rows of 16 pieces of 16 B, contiguous in HBM; every load is issued
+    // before the first LDS write so the latencies overlap
+    uint4* gsl = reinterpret_cast<uint4*>(act + (size_t)blockIdx.x * NROW * CH);
     {
-        constexpr int TOTAL = SLAB_POS * 16;
+        constexpr int TOTAL = NROW * 16;
         constexpr int NLD = (TOTAL + NT - 1) / NT;
         uint4 tmp[NLD];
 #pragma unroll
@@ -183,43 +195,45 @@ k_tower128(const uint8_t* __restrict__ wts /* fragment order, two convs */, cons
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
             const int i = tid + j * NT;
-            if (i < TOTAL) {
-                const int o = (i >> 4) * ROWB + (i & 15) * 16;
-                *reinterpret_cast<uint4*>(lds + o) = tmp[j];
-                *reinterpret_cast<uint4*>(lds + SLAB_BYTES + o) = make_uint4(0, 0, 0, 0);
-            }
+            if (i < TOTAL) *reinterpret_cast<uint4*>(lds + (i >> 4) * ROWB + (i & 15) * 16) = tmp[j];
         }
+        if (tid < 32) *reinterpret_cast<uint4*>(lds + (tid >> 4) * SLAB_BYTES + ZROW * ROWB + (tid & 15) * 16) = make_uint4(0, 0, 0, 0);
     }
 
-    // this wave's three position tiles
-    int qrow[3];
-    bool keep[3];
+    // this wave's four row tiles; bit k of vmask = tap k stays on the board
+    int qrow[NTILE], vmask[NTILE];
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const int R = (wp * 3 + t) * 32 + col;
-        const int bl = R / 48, o = R - bl * 48;
-        qrow[t] = (bl * BPOS + 9 + o) * ROWB;
-        keep[t] = (o & 7) != 7;
+    for (int t = 0; t < NTILE; ++t) {
+        const int R = (wp * NTILE + t) * 32 + col;
+        const int o = R % BPOS, y = o / 7, x = o - 7 * y;
+        int m = 0;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            m |= (yy >= 0 && yy < 6 && xx >= 0 && xx < 7) << tap;
+        }
+        qrow[t] = R * ROWB;
+        vmask[t] = R < NROW ? m : 0;
     }
-    f32x16 acc[3];
+    f32x16 acc[NTILE];
     {
         const float* bp = bias + CH + 32 * wc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float bv = bp[(r & 3) + 8 * (r >> 2) + 4 * h];
-            acc[0][r] = bv; acc[1][r] = bv; acc[2][r] = bv;
+#pragma unroll
+            for (int t = 0; t < NTILE; ++t) acc[t][r] = bv;
         }
     }
     __syncthreads();
 
 #pragma unroll 1
     for (int g = 0; g < total; g += 2) {
-        tower_tap(acc, bufa, bufb, wts, bias, lds, qrow, keep, g, total, wc, h, lane);
-        tower_tap(acc, bufb, bufa, wts, bias, lds, qrow, keep, g + 1, total, wc, h, lane);
+        tower_tap(acc, bufa, bufb, wts, bias, lds, qrow, vmask, g, total, wc, h, lane);
+        tower_tap(acc, bufb, bufa, wts, bias, lds, qrow, vmask, g + 1, total, wc, h, lane);
     }
 
-    // slab rows [9, 249) hold the four boards (the rows between boards are zero on both sides)
-    for (int i = 9 * 16 + tid; i < 249 * 16; i += NT)
+    for (int i = tid; i < NROW * 16; i += NT)
         gsl[i] = *reinterpret_cast<const uint4*>(lds + (i >> 4) * ROWB + (i & 15) * 16);
 }
 
@@ -239,7 +253,7 @@ __global__ void __launch_bounds__(256) k_heads128(const uint8_t* __restrict__ bl
         const int b = i / 42, cell = i - b * 42;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
         if (board0 + b < n) {
-            const __bf16* xs = act + ((size_t)1 + (board0 + b) * BPOS + 8 + (cell / 7) * 8 + cell % 7) * CH;
+            const __bf16* xs = act + ((size_t)(board0 + b) * BPOS + cell) * CH;
             for (int c = 0; c < CH; c += 8) {
                 const bf16x8 xv = *reinterpret_cast<const bf16x8*>(xs + c);
 #pragma unroll
@@ -306,7 +320,7 @@ extern "C" {
 
 int az_c4net128_blob_bytes(void) { return G_BLOB_BYTES; }
 
-// one activation tensor; the caller zero-fills the workspace once (zero rows are never written)
+// one activation tensor, padded to whole workgroups of boards
 long az_c4net128_workspace_bytes(int32_t n) { return n < 0 ? -1 : (long)(act_positions(n) * CH * 2); }
 
 int az_c4net128_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uint64_t* leaf_bb, int32_t n,
@@ -315,7 +329,7 @@ int az_c4net128_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uint
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     __bf16* t0 = reinterpret_cast<__bf16*>(workspace);
-    const int lds = 2 * SLAB_POS * ROWB;
+    const int lds = 2 * SLAB_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower128), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -324,7 +338,7 @@ int az_c4net128_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uint
         attr_set = true;
     }
     const int ngroups = (n + GB - 1) / GB;
-    const long stem_threads = (long)n * 48 * 8;
+    const long stem_threads = (long)act_positions(n) * 8;
     hipLaunchKernelGGL(k_stem128, dim3((unsigned)((stem_threads + 255) / 256)), dim3(256), 0, st, blob, leaf_bb, (int)n, t0);
     const float* bias = reinterpret_cast<const float*>(blob + G_BIAS);
     if (num_blocks > 0)
