@@ -27,7 +27,6 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define NROW (GB * BPOS)            // 252 real rows per slab
 #define ZROW NROW                   // the all-zero row
 #define ROWB 272                    // LDS row stride in bytes: 256 + 16 (17 slots of 16 B, odd)
-#define SLAB_BYTES ((NROW + 1) * ROWB)
 #define NT 512
 
 // blob layout (bytes); must match alphazero_amd/net.py pack_c4_blob_128
@@ -105,80 +104,141 @@ __global__ void __launch_bounds__(256) k_stem128(const uint8_t* __restrict__ blo
 // order [conv][tap][32-channel tile][k-step][lane][8 bf16] and every lane reads its 16 bytes
 // straight from L2 one tap ahead of use, alternating between two register buffers; the prefetch
 // runs across conv boundaries, so the only bubble per conv is the epilogue and its barrier.
+// The 18 taps of a block are unrolled, so tap geometry, buffer roles and epilogue kind are static.
 #define CONV_BYTES (9 * CH * CH * 2)
 #define NTILE 4
+#define SLAB_ROWS (NROW + 1 + NTILE)    // real rows, the zero row, landing rows for the idle lanes
+#undef SLAB_BYTES
+#define SLAB_BYTES (SLAB_ROWS * ROWB)
+#define BIAS_OFF (2 * SLAB_BYTES)
 
-__device__ __forceinline__ void load_wfrag(uint4 (&buf)[8], const uint8_t* __restrict__ wts, int g, int wc, int lane) {
-    const int conv = (g / 9) & 1, tap = g % 9;
-    const uint4* wq = reinterpret_cast<const uint4*>(wts + (size_t)conv * CONV_BYTES) + ((tap * 4 + wc) * 8) * 64 + lane;
+struct TowerCtx {
+    const uint8_t* wts;
+    uint8_t* lds;
+    int qrow[NTILE];     // byte offset of the lane's row in a slab, per tile
+    int vmask[NTILE];    // bit k: tap k of that row stays on the board (0 for idle lanes)
+    int wc, h, lane;
+};
+
+template <int CONV, int TAP>
+__device__ __forceinline__ void load_wfrag(uint4 (&buf)[8], const TowerCtx& c) {
+    // uniform base + one 32-bit lane offset (kept opaque so that 18 taps of 64-bit addresses are not
+    // precomputed outside the block loop); the k-step is the instruction's immediate offset
+    const uint8_t* base = c.wts + (size_t)CONV * CONV_BYTES + TAP * (4 * 8 * 64 * 16);
+    uint32_t voff = (uint32_t)(c.wc * 8 * 64 + c.lane) * 16;
+    asm volatile("" : "+v"(voff));
 #pragma unroll
-    for (int s = 0; s < 8; ++s) buf[s] = wq[s * 64];
+    for (int s = 0; s < 8; ++s) buf[s] = *reinterpret_cast<const uint4*>(base + (s >> 2) * 4096 + voff + (s & 3) * 1024);
 }
 
-__device__ __forceinline__ void tower_tap(f32x16 (&acc)[NTILE], const uint4 (&cur)[8], uint4 (&nxt)[8],
-                                          const uint8_t* __restrict__ wts, const float* __restrict__ bias, uint8_t* lds,
-                                          const int (&qrow)[NTILE], const int (&vmask)[NTILE], int g, int total, int wc,
-                                          int h, int lane) {
-    const int conv = g / 9, tap = g - conv * 9;
-    if (g + 1 < total) load_wfrag(nxt, wts, g + 1, wc, lane);
-    const uint8_t* src = lds + (conv & 1) * SLAB_BYTES + h * 16;
-    const int delta = ((tap / 3 - 1) * 7 + (tap % 3 - 1)) * ROWB;
-    int off[NTILE];
-#pragma unroll
-    for (int t = 0; t < NTILE; ++t) off[t] = ((vmask[t] >> tap) & 1) ? qrow[t] + delta : ZROW * ROWB;
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        bf16x8 a;
-        __builtin_memcpy(&a, &cur[s], 16);
-#pragma unroll
-        for (int t = 0; t < NTILE; ++t) {
-            const bf16x8 b = *reinterpret_cast<const bf16x8*>(src + off[t] + s * 32);
-            acc[t] = MFMA(a, b, acc[t]);
-        }
-    }
-    if (tap != 8) return;
-    // epilogue: register r = channel 32*wc + (r&3) + 8*(r>>2) + 4*h of the lane's row
-    const bool second = conv & 1;
-    uint8_t* dst = lds + (second ? 0 : SLAB_BYTES) + (32 * wc + 4 * h) * 2;
+template <int TAP>
+__device__ __forceinline__ void tap_offsets(int (&off)[NTILE], const TowerCtx& c) {
+    constexpr int delta = ((TAP / 3 - 1) * 7 + (TAP % 3 - 1)) * ROWB;
 #pragma unroll
     for (int t = 0; t < NTILE; ++t) {
-        if (vmask[t] == 0) continue;            // idle rows past the last board (the centre tap is valid on every real row)
+        int m = c.vmask[t];
+        asm volatile("" : "+v"(m));      // recomputed per tap: hoisting 18 taps of offsets out of the block loop would spill
+        off[t] = ((m >> TAP) & 1) ? c.qrow[t] + delta : ZROW * ROWB;
+    }
+}
+
+// One tap = 8 k-steps of 4 MFMAs.  Activation fragments are read one k-step ahead of the MFMAs that
+// consume them (b0 / b1 alternate), and the last k-step already fetches the next tap's first
+// fragments, so an LDS round trip is never on the matrix pipe's critical path.  On entry b0 holds
+// k-step 0 of this tap.  Tap 0 starts the accumulators from zero; tap 8 ends with the epilogue
+// (bias, residual on the second conv of a block, ReLU, bf16, write to the other slab) and a barrier.
+template <int CONV, int TAP>
+__device__ __forceinline__ void tower_tap(f32x16 (&acc)[NTILE], const uint4 (&cur)[8], uint4 (&nxt)[8], bf16x8 (&b0)[NTILE],
+                                          const TowerCtx& c, bool more) {
+    constexpr bool SECOND = CONV == 1;
+    if (TAP < 8) load_wfrag<CONV, (TAP + 1) % 9>(nxt, c);
+    else if (more) load_wfrag<1 - CONV, 0>(nxt, c);
+    const uint8_t* src = c.lds + CONV * SLAB_BYTES + c.h * 16;
+    int off[NTILE], offn[NTILE];
+    tap_offsets<TAP>(off, c);
+    if (TAP < 8) tap_offsets<(TAP + 1) % 9>(offn, c);
+    bf16x8 b1[NTILE];
+#pragma unroll
+    for (int s = 0; s < 8; s += 2) {
+        bf16x8 a;
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) b1[t] = *reinterpret_cast<const bf16x8*>(src + off[t] + (s + 1) * 32);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_memcpy(&a, &cur[s], 16);
+        if (TAP == 0 && s == 0) {
+            const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < NTILE; ++t) acc[t] = MFMA(a, b0[t], zero);
+        } else {
+#pragma unroll
+            for (int t = 0; t < NTILE; ++t) acc[t] = MFMA(a, b0[t], acc[t]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 < 8) {
+#pragma unroll
+            for (int t = 0; t < NTILE; ++t) b0[t] = *reinterpret_cast<const bf16x8*>(src + off[t] + (s + 2) * 32);
+        } else if (TAP < 8) {
+#pragma unroll
+            for (int t = 0; t < NTILE; ++t) b0[t] = *reinterpret_cast<const bf16x8*>(src + offn[t]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_memcpy(&a, &cur[s + 1], 16);
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) acc[t] = MFMA(a, b1[t], acc[t]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (TAP < 8) return;
+
+    // epilogue: register r = channel 32*wc + (r&3) + 8*(r>>2) + 4*h of the lane's row
+    uint8_t* dst = c.lds + (SECOND ? 0 : SLAB_BYTES) + (32 * c.wc + 4 * c.h) * 2;
+    const float* bp = reinterpret_cast<const float*>(c.lds + BIAS_OFF) + CONV * CH + 32 * c.wc + 4 * c.h;
+    float4 bv[4];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) bv[gq] = *reinterpret_cast<const float4*>(bp + 8 * gq);
+    uint2 r[NTILE][4];
+    if (SECOND) {
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) r[t][gq] = *reinterpret_cast<const uint2*>(dst + c.qrow[t] + 16 * gq);
+    }
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) {
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
-            uint8_t* pos = dst + qrow[t] + 16 * gq;
-            float x0 = acc[t][4 * gq], x1 = acc[t][4 * gq + 1], x2 = acc[t][4 * gq + 2], x3 = acc[t][4 * gq + 3];
-            if (second) {
-                const uint2 r = *reinterpret_cast<const uint2*>(pos);
-                x0 += __uint_as_float(r.x << 16); x1 += __uint_as_float(r.x & 0xFFFF0000u);
-                x2 += __uint_as_float(r.y << 16); x3 += __uint_as_float(r.y & 0xFFFF0000u);
+            float x0 = acc[t][4 * gq] + bv[gq].x, x1 = acc[t][4 * gq + 1] + bv[gq].y;
+            float x2 = acc[t][4 * gq + 2] + bv[gq].z, x3 = acc[t][4 * gq + 3] + bv[gq].w;
+            if (SECOND) {
+                x0 += __uint_as_float(r[t][gq].x << 16); x1 += __uint_as_float(r[t][gq].x & 0xFFFF0000u);
+                x2 += __uint_as_float(r[t][gq].y << 16); x3 += __uint_as_float(r[t][gq].y & 0xFFFF0000u);
             }
             bf16x4 y;
-            y[0] = (__bf16)fmaxf(x0, 0.0f); y[1] = (__bf16)fmaxf(x1, 0.0f);
-            y[2] = (__bf16)fmaxf(x2, 0.0f); y[3] = (__bf16)fmaxf(x3, 0.0f);
-            *reinterpret_cast<bf16x4*>(pos) = y;
+            y[0] = (__bf16)__builtin_amdgcn_fmed3f(x0, 0.0f, INFINITY); y[1] = (__bf16)__builtin_amdgcn_fmed3f(x1, 0.0f, INFINITY);
+            y[2] = (__bf16)__builtin_amdgcn_fmed3f(x2, 0.0f, INFINITY); y[3] = (__bf16)__builtin_amdgcn_fmed3f(x3, 0.0f, INFINITY);
+            *reinterpret_cast<bf16x4*>(dst + c.qrow[t] + 16 * gq) = y;
         }
     }
-    // accumulators restart from the next conv's bias
-    const float* bp = bias + (second ? 1 : 2) * CH + 32 * wc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float bv = bp[(r & 3) + 8 * (r >> 2) + 4 * h];
-#pragma unroll
-        for (int t = 0; t < NTILE; ++t) acc[t][r] = bv;
-    }
     __syncthreads();
+    if (more) {                                // first fragments of the next conv, from the slab just written
+        const uint8_t* src2 = c.lds + (SECOND ? 0 : SLAB_BYTES) + c.h * 16;
+        tap_offsets<0>(off, c);
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) b0[t] = *reinterpret_cast<const bf16x8*>(src2 + off[t]);
+    }
 }
 
 __global__ void __launch_bounds__(NT, 2)
 k_tower128(const uint8_t* __restrict__ wts /* fragment order, two convs */, const float* __restrict__ bias /* [3][128] */,
            __bf16* __restrict__ act, int num_blocks) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // [2][NROW + 1][ROWB]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, col = lane & 31;
-    const int wc = wave & 3, wp = wave >> 2;
-    const int total = 18 * num_blocks;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // [2][SLAB_ROWS][ROWB], then f32 [2][128] biases
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 31;
+    const int wp = wave >> 2;
+    TowerCtx c;
+    c.wts = wts; c.lds = lds; c.wc = wave & 3; c.h = lane >> 5; c.lane = lane;
 
     uint4 bufa[8], bufb[8];
-    load_wfrag(bufa, wts, 0, wc, lane);
+    load_wfrag<0, 0>(bufa, c);
+    if (tid < 2 * CH) reinterpret_cast<float*>(lds + BIAS_OFF)[tid] = bias[CH + tid];   // conv biases
 
     // stage the six boards: 252 rows of 16 pieces of 16 B, contiguous in HBM; every load is issued
     // before the first LDS write so the latencies overlap
@@ -200,8 +260,8 @@ k_tower128(const uint8_t* __restrict__ wts /* fragment order, two convs */, cons
         if (tid < 32) *reinterpret_cast<uint4*>(lds + (tid >> 4) * SLAB_BYTES + ZROW * ROWB + (tid & 15) * 16) = make_uint4(0, 0, 0, 0);
     }
 
-    // this wave's four row tiles; bit k of vmask = tap k stays on the board
-    int qrow[NTILE], vmask[NTILE];
+    // this wave's four row tiles.  The four lanes past row 251 read the zero row for every tap and
+    // write their results to landing rows behind it, so the epilogue needs no lane mask.
 #pragma unroll
     for (int t = 0; t < NTILE; ++t) {
         const int R = (wp * NTILE + t) * 32 + col;
@@ -212,25 +272,40 @@ k_tower128(const uint8_t* __restrict__ wts /* fragment order, two convs */, cons
             const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
             m |= (yy >= 0 && yy < 6 && xx >= 0 && xx < 7) << tap;
         }
-        qrow[t] = R * ROWB;
-        vmask[t] = R < NROW ? m : 0;
+        c.qrow[t] = (R < NROW ? R : R + 1) * ROWB;
+        c.vmask[t] = R < NROW ? m : 0;
     }
     f32x16 acc[NTILE];
-    {
-        const float* bp = bias + CH + 32 * wc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float bv = bp[(r & 3) + 8 * (r >> 2) + 4 * h];
-#pragma unroll
-            for (int t = 0; t < NTILE; ++t) acc[t][r] = bv;
-        }
-    }
     __syncthreads();
+    bf16x8 b0[NTILE];
+    {
+        int off[NTILE];
+        tap_offsets<0>(off, c);
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) b0[t] = *reinterpret_cast<const bf16x8*>(lds + c.h * 16 + off[t]);
+    }
 
 #pragma unroll 1
-    for (int g = 0; g < total; g += 2) {
-        tower_tap(acc, bufa, bufb, wts, bias, lds, qrow, vmask, g, total, wc, h, lane);
-        tower_tap(acc, bufb, bufa, wts, bias, lds, qrow, vmask, g + 1, total, wc, h, lane);
+    for (int blk = 0; blk < num_blocks; ++blk) {
+        const bool more = blk + 1 < num_blocks;
+        tower_tap<0, 0>(acc, bufa, bufb, b0, c, true);
+        tower_tap<0, 1>(acc, bufb, bufa, b0, c, true);
+        tower_tap<0, 2>(acc, bufa, bufb, b0, c, true);
+        tower_tap<0, 3>(acc, bufb, bufa, b0, c, true);
+        tower_tap<0, 4>(acc, bufa, bufb, b0, c, true);
+        tower_tap<0, 5>(acc, bufb, bufa, b0, c, true);
+        tower_tap<0, 6>(acc, bufa, bufb, b0, c, true);
+        tower_tap<0, 7>(acc, bufb, bufa, b0, c, true);
+        tower_tap<0, 8>(acc, bufa, bufb, b0, c, true);
+        tower_tap<1, 0>(acc, bufb, bufa, b0, c, true);
+        tower_tap<1, 1>(acc, bufa, bufb, b0, c, true);
+        tower_tap<1, 2>(acc, bufb, bufa, b0, c, true);
+        tower_tap<1, 3>(acc, bufa, bufb, b0, c, true);
+        tower_tap<1, 4>(acc, bufb, bufa, b0, c, true);
+        tower_tap<1, 5>(acc, bufa, bufb, b0, c, true);
+        tower_tap<1, 6>(acc, bufb, bufa, b0, c, true);
+        tower_tap<1, 7>(acc, bufa, bufb, b0, c, true);
+        tower_tap<1, 8>(acc, bufb, bufa, b0, c, more);
     }
 
     for (int i = tid; i < NROW * 16; i += NT)
@@ -329,7 +404,7 @@ int az_c4net128_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uint
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     __bf16* t0 = reinterpret_cast<__bf16*>(workspace);
-    const int lds = 2 * SLAB_BYTES;
+    const int lds = BIAS_OFF + 2 * CH * 4;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower128), hipFuncAttributeMaxDynamicSharedMemorySize,
