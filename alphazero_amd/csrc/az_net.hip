@@ -121,13 +121,14 @@ __device__ __forceinline__ void load_taps(bf16x8 (&f)[6], const uint8_t* base, i
     }
 }
 
-// One 3x3 conv over the wave's own two boards (3 tiles of 32 positions): src -> dst (+ residual
+// One 3x3 conv over the wave's own two boards (3 tiles of 32 positions; 2 tiles when only the first
+// board holds a leaf): src -> dst (+ residual
 // read from dst when RES).  A wave's tiles only ever read positions of its own boards and the
 // never-written zero rows, so the tower needs no workgroup barrier: LDS operations of one wave
 // complete in issue order.  Loads run one row of taps ahead of the MFMAs that consume them.
 template <bool RES>
 __device__ __forceinline__ void conv3x3(const Weights& w, const uint8_t* src, uint8_t* dst, const float* bias,
-                                        int wave, int lane) {
+                                        int wave, int lane, bool two) {
     const int h = lane >> 5;
     int pos[TILES_PER_WAVE];
     bool keep[TILES_PER_WAVE];
@@ -144,6 +145,7 @@ __device__ __forceinline__ void conv3x3(const Weights& w, const uint8_t* src, ui
     load_taps(fa, base[0], 0);
 #pragma unroll
     for (int t = 0; t < TILES_PER_WAVE; ++t) {
+        if (t == 2 && !two) break;                 // a single board ends inside the second tile
         f32x16 acc = bias_acc(bias, h);
         load_taps(fb, base[t], 1);
 #pragma unroll
@@ -164,11 +166,11 @@ __device__ __forceinline__ void conv3x3(const Weights& w, const uint8_t* src, ui
 
 // stem conv 2 -> C straight from bitboards: B[k][pos], k = tap*2 + plane (18 of 32 used)
 __device__ __forceinline__ void stem(const uint8_t* blob, const uint64_t* leaf_bb, const int* games, uint8_t* dst,
-                                     const float* bias, int wave, int lane) {
+                                     const float* bias, int wave, int lane, int ntiles) {
     const int h = lane >> 5;
     const bf16x8 a0 = frag_ptr(blob, OFF_SF, lane)[0], a1 = frag_ptr(blob, OFF_SF, lane)[64];
 #pragma unroll 1
-    for (int t = 0; t < TILES_PER_WAVE; ++t) {
+    for (int t = 0; t < ntiles; ++t) {
         const int R = (wave * TILES_PER_WAVE + t) * 32 + (lane & 31);
         const int b = R / 48, o = R - b * 48;
         const int pos = b * BOARD_POS + POS0 + o;
@@ -236,21 +238,24 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
     if (tid < 64) reinterpret_cast<float*>(scr + S_BP)[tid] = reinterpret_cast<const float*>(blob + OFF_BP)[tid];
 
     // ---- which leaves does each wave evaluate?  Only leaves that need the network (kind EVAL or
-    // ROOT in leaf_info) are packed, two per wave-task; task t goes to wave slot t % (8*gridDim),
-    // slot s = workgroup s % gridDim, wave s / gridDim, so a partial last round is spread over all
-    // CUs.  Every workgroup scans the (L2-resident) leaf_info array itself: no extra launch, no
-    // atomics, deterministic packing order.
+    // ROOT in leaf_info) count.  The E of them are dealt out in rank order, as evenly as possible:
+    // wave slot s takes base + (s < rem) consecutive ranks (base = E / slots, rem = E % slots) and
+    // walks through them two at a time.  Slot s = workgroup s % gridDim, wave s / gridDim: the slots
+    // with one leaf more are waves 0..3 first, which sit on four different SIMDs.  Every workgroup
+    // scans the (L2-resident) leaf_info array itself: no extra launch, no atomics, deterministic.
     int* tlist = reinterpret_cast<int*>(scr + S_TL);
     int* wtot = reinterpret_cast<int*>(scr + S_WT);
     if (tid < 8 * MAXIT * 2) tlist[tid] = -1;
     __syncthreads();
     const int NW = (int)gridDim.x * 8;
     if (!leaf_info) {
-        // dense mode: every leaf is evaluated, task t = leaves 2t, 2t+1
+        // dense mode: every leaf is evaluated, rank = leaf index
         if (tid < 8 * MAXIT * 2) {
-            const int w = tid / (MAXIT * 2), k = (tid >> 1) % MAXIT;
-            const int leaf = 2 * ((int)blockIdx.x + (int)gridDim.x * w + NW * k) + (tid & 1);
-            if (leaf < n) tlist[tid] = leaf;
+            const int w = tid / (MAXIT * 2), pos = tid % (MAXIT * 2);
+            const int slot = (int)blockIdx.x + (int)gridDim.x * w;
+            const int base = n / NW, rem = n - base * NW;
+            const int start = slot * base + min(slot, rem), len = base + (slot < rem);
+            if (pos < len) tlist[tid] = start + pos;
         }
     } else {
         // thread t owns games [t*per, t*per + per); `per` is rounded up to a multiple of 4 so the
@@ -288,19 +293,23 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
             before += (w < wave) ? t : 0;
             total += t;
         }
-        // ranks [rank0, rank0 + cnt) belong to this thread.  gridDim is a power of two (log2 in
-        // grid_shift), so "is task t mine" is a mask test.
-        int rank = before + incl - cnt;
-        (void)total;
-        while (mask) {
-            const int j = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            const int t = rank >> 1;
-            if ((t & ((int)gridDim.x - 1)) == (int)blockIdx.x) {
-                const int w = (t >> grid_shift) & 7, k = t >> (grid_shift + 3);
-                if (k < MAXIT) tlist[(w * MAXIT + k) * 2 + (rank & 1)] = g0 + j;
+        // ranks [rank, rank + cnt) belong to this thread: find the slot of the first one with one
+        // division, then step through slots as the ranks run out of them
+        if (cnt) {
+            const int rank = before + incl - cnt;
+            const int base = total / NW, rem = total - base * NW;
+            const int big = rem * (base + 1);           // ranks below this sit in slots of base + 1
+            int slot, pos;
+            if (rank < big) { slot = rank / (base + 1); pos = rank - slot * (base + 1); }
+            else { const int q = (rank - big) / base; slot = rem + q; pos = rank - big - q * base; }
+            int len = base + (slot < rem);
+            while (mask) {
+                const int j = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                if ((slot & ((int)gridDim.x - 1)) == (int)blockIdx.x && pos < MAXIT * 2)
+                    tlist[(slot >> grid_shift) * MAXIT * 2 + pos] = g0 + j;
+                if (++pos == len) { ++slot; pos = 0; len = base + (slot < rem); }
             }
-            ++rank;
         }
     }
     __syncthreads();
@@ -321,10 +330,12 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
         if (games[0] < 0) break;
         const uint8_t* sblob = blob;
         asm volatile("" : "+s"(sblob));
-        stem(sblob, leaf_bb, games, bufY, sbias, wave, lane);
+        const bool two = games[1] >= 0;
+        const int ntiles = two ? TILES_PER_WAVE : 2;
+        stem(sblob, leaf_bb, games, bufY, sbias, wave, lane, ntiles);
         for (int blk = 0; blk < num_blocks; ++blk) {
-            conv3x3<false>(w1, bufY, bufX, sbias + 32, wave, lane);
-            conv3x3<true>(w2, bufX, bufY, sbias + 64, wave, lane);
+            conv3x3<false>(w1, bufY, bufX, sbias + 32, wave, lane, two);
+            conv3x3<true>(w2, bufX, bufY, sbias + 64, wave, lane, two);
         }
 
         // Head weights are fetched here, per task: hoisted above the loop they would be spilled to
@@ -336,7 +347,7 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
         {
             const bf16x8 a0 = frag_ptr(hblob, OFF_HF, lane)[0], a1 = frag_ptr(hblob, OFF_HF, lane)[64];
 #pragma unroll 1
-            for (int t = 0; t < TILES_PER_WAVE; ++t) {
+            for (int t = 0; t < ntiles; ++t) {
                 const int R = (wave * TILES_PER_WAVE + t) * 32 + (lane & 31);
                 const int b = R / 48, o = R - b * 48;
                 const uint8_t* base = bufY + (b * BOARD_POS + POS0 + o) * PSTRIDE + h * 16;
@@ -439,8 +450,8 @@ int az_c4net_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uint64_
             return -2;
         attr_set = true;
     }
-    // one persistent workgroup per CU at most; a power of two so tasks map to waves by bit masks; with
-    // fewer tasks than wave slots the tasks are spread one per CU first (slot s = WG s % grid)
+    // one persistent workgroup per CU at most; a power of two so slots map to waves by bit masks; with
+    // fewer leaves than wave slots they are spread over the CUs first (slot s = WG s % grid)
     const int ntasks = (n + 1) / 2;
     int grid_shift = 0;
     while ((1 << grid_shift) < ntasks && grid_shift < 8) ++grid_shift;

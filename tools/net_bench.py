@@ -18,6 +18,7 @@ ap.add_argument('--n', type=str, default='8192')
 ap.add_argument('--blocks', type=str, default='6')
 ap.add_argument('--ch', type=int, default=32)
 ap.add_argument('--iters', type=int, default=50)
+ap.add_argument('--active', type=float, default=0.583, help='fraction of leaves that need the net in the sparse case')
 args = ap.parse_args()
 
 rng = np.random.RandomState(0)
@@ -31,9 +32,12 @@ for n_, blocks in [(int(a), int(b)) for a in args.n.split(',') for b in args.blo
     net = FusedC4Net.from_module(AlphaZeroC4(blocks, args.ch).eval(), 'cuda')
     flops = args.n * (2 * blocks * 2 * 9 * args.ch * args.ch * 42 + 2 * 9 * 2 * args.ch * 42)
     # interleaved rounds in one process: dense (no packing scan) vs packed with every leaf active
-    res = {'dense': [], 'packed': []}
+    act = torch.from_numpy(rng.rand(args.n) < args.active).cuda()
+    sparse = torch.where(act, info, torch.zeros_like(info))
+    nact = int(act.sum())
+    res = {'dense': [], 'packed': [], 'sparse': []}
     for rnd in range(5):
-        for name, inf in (('dense', None), ('packed', info)):
+        for name, inf in (('dense', None), ('packed', info), ('sparse', sparse)):
             for _ in range(3):
                 net(bb, inf)
             torch.cuda.synchronize()
@@ -46,5 +50,9 @@ for n_, blocks in [(int(a), int(b)) for a in args.n.split(',') for b in args.blo
             res[name].append(a.elapsed_time(b) * 1e3 / args.iters)
     for name, v in res.items():
         us = sorted(v)[len(v) // 2]
+        if name == 'sparse':
+            print(f'blocks={blocks} ch={args.ch} n={args.n} sparse ({nact} active): median {us:.1f} us (min {min(v):.1f}), '
+                  f'{flops * nact / args.n / us / 1e6:.1f} TFLOP/s')
+            continue
         print(f'blocks={blocks} ch={args.ch} n={args.n} {name}: median {us:.1f} us (min {min(v):.1f}), '
               f'{flops / us / 1e6:.1f} TFLOP/s')
