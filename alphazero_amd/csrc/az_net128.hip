@@ -25,7 +25,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define GB 6                        // boards per workgroup
 #define BPOS 42                     // positions per board
 #define NROW (GB * BPOS)            // 252 real rows per slab
-#define ZROW NROW                   // the all-zero row
+#define ZROW0 256                   // 16 all-zero rows, one per LDS slot residue (row mod 16)
 #define ROWB 272                    // LDS row stride in bytes: 256 + 16 (17 slots of 16 B, odd)
 #define NT 512
 
@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(256) k_stem128(const uint8_t* __restrict__ blo
 // The 18 taps of a block are unrolled, so tap geometry, buffer roles and epilogue kind are static.
 #define CONV_BYTES (9 * CH * CH * 2)
 #define NTILE 4
-#define SLAB_ROWS (NROW + 1 + NTILE)    // real rows, the zero row, landing rows for the idle lanes
+#define SLAB_ROWS (ZROW0 + 16)           // 252 real rows, 4 landing rows for the idle lanes, 16 zero rows
 #undef SLAB_BYTES
 #define SLAB_BYTES (SLAB_ROWS * ROWB)
 #define BIAS_OFF (2 * SLAB_BYTES)
@@ -133,12 +133,19 @@ __device__ __forceinline__ void load_wfrag(uint4 (&buf)[8], const TowerCtx& c) {
 
 template <int TAP>
 __device__ __forceinline__ void tap_offsets(int (&off)[NTILE], const TowerCtx& c) {
-    constexpr int delta = ((TAP / 3 - 1) * 7 + (TAP % 3 - 1)) * ROWB;
+    // An off-board tap reads the zero row with the same residue mod 16 as the row it replaces: the
+    // 16 lanes of a ds_read_b128 group then still fall on 16 different 16-byte slots (row stride =
+    // 17 slots), which one shared zero row would break for every group with a border cell.
+    // (Tiles start at multiples of 32 rows, so that residue is the same for the lane's four tiles.)
+    constexpr int delta = (TAP / 3 - 1) * 7 + (TAP % 3 - 1);
+    int col = c.lane;
+    asm volatile("" : "+v"(col));        // recomputed per tap: hoisting 18 taps of offsets out of the block loop would spill
+    const int zoff = (ZROW0 + ((col + delta) & 15)) * ROWB;
 #pragma unroll
     for (int t = 0; t < NTILE; ++t) {
         int m = c.vmask[t];
-        asm volatile("" : "+v"(m));      // recomputed per tap: hoisting 18 taps of offsets out of the block loop would spill
-        off[t] = ((m >> TAP) & 1) ? c.qrow[t] + delta : ZROW * ROWB;
+        asm volatile("" : "+v"(m));
+        off[t] = ((m >> TAP) & 1) ? c.qrow[t] + delta * ROWB : zoff;
     }
 }
 
@@ -257,11 +264,12 @@ k_tower128(const uint8_t* __restrict__ wts /* fragment order, two convs */, cons
             const int i = tid + j * NT;
             if (i < TOTAL) *reinterpret_cast<uint4*>(lds + (i >> 4) * ROWB + (i & 15) * 16) = tmp[j];
         }
-        if (tid < 32) *reinterpret_cast<uint4*>(lds + (tid >> 4) * SLAB_BYTES + ZROW * ROWB + (tid & 15) * 16) = make_uint4(0, 0, 0, 0);
+        // zero rows of both slabs: 2 x 16 rows x 16 pieces
+        *reinterpret_cast<uint4*>(lds + (tid >> 8) * SLAB_BYTES + (ZROW0 + ((tid >> 4) & 15)) * ROWB + (tid & 15) * 16) = make_uint4(0, 0, 0, 0);
     }
 
-    // this wave's four row tiles.  The four lanes past row 251 read the zero row for every tap and
-    // write their results to landing rows behind it, so the epilogue needs no lane mask.
+    // this wave's four row tiles.  The four lanes past row 251 read zero rows for every tap and
+    // write their results to the landing rows 252..255, so the epilogue needs no lane mask.
 #pragma unroll
     for (int t = 0; t < NTILE; ++t) {
         const int R = (wp * NTILE + t) * 32 + col;
@@ -272,7 +280,7 @@ k_tower128(const uint8_t* __restrict__ wts /* fragment order, two convs */, cons
             const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
             m |= (yy >= 0 && yy < 6 && xx >= 0 && xx < 7) << tap;
         }
-        c.qrow[t] = (R < NROW ? R : R + 1) * ROWB;
+        c.qrow[t] = R * ROWB;
         c.vmask[t] = R < NROW ? m : 0;
     }
     f32x16 acc[NTILE];
