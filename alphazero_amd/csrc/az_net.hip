@@ -50,9 +50,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define S_W2 (S_B1 + 1024)                    // float[256] value FC2 weights
 #define S_BP (S_W2 + 1024)                    // float[64]  policy FC bias
 #define S_PW (S_BP + 256)                     // per-wave head scratch, PW_BYTES each:
-#define PW_HP 0                               //   bf16 [2][96] policy planes, k = ch*42 + cell
-#define PW_HV 384                             //   bf16 [2][48] value plane
-#define PW_LG 576                             //   float [2][64] cell logits
+#define PW_HP 0                               //   bf16 [4][96] policy planes, k = ch*42 + cell
+#define PW_HV 768                             //   bf16 [4][48] value plane
+#define PW_LG 0                               //   float [4][64] cell logits, written over the planes
 #define PW_BYTES 1152
 #define MAXIT 8                               // wave-tasks per wave per launch (n <= 32768)
 #define S_TL (S_PW + 8 * PW_BYTES)            // int [8 waves][MAXIT][2] leaf index of each board
@@ -325,13 +325,14 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
     const float* sbp = reinterpret_cast<const float*>(scr + S_BP);
     const int* mylist = tlist + wave * MAXIT * 2;
 
+    int hg0 = -1, hg1 = -1, hg2 = -1, hg3 = -1;   // leaves whose head planes wait in hp / hv (boards 0..3)
     for (int iter = 0; iter < MAXIT; ++iter) {
         const int games[2] = {mylist[2 * iter], mylist[2 * iter + 1]};
         if (games[0] < 0) break;
-        const uint8_t* sblob = blob;
-        asm volatile("" : "+s"(sblob));
         const bool two = games[1] >= 0;
         const int ntiles = two ? TILES_PER_WAVE : 2;
+        const uint8_t* sblob = blob;
+        asm volatile("" : "+s"(sblob));
         stem(sblob, leaf_bb, games, bufY, sbias, wave, lane, ntiles);
         for (int blk = 0; blk < num_blocks; ++blk) {
             conv3x3<false>(w1, bufY, bufX, sbias + 32, wave, lane, two);
@@ -343,7 +344,10 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
         // loads stay below this point.
         const uint8_t* hblob = blob;
         asm volatile("" : "+s"(hblob));
-        // ---- 1x1 head convs as one 2-step MFMA: rows 0,1 = policy planes, row 2 = value plane
+        // ---- 1x1 head convs as one 2-step MFMA: rows 0,1 = policy planes, row 2 = value plane.
+        // Tasks alternate between the two halves of the wave's head scratch (boards 0,1 / 2,3).
+        const int half = iter & 1;
+        if (half) { hg2 = games[0]; hg3 = games[1]; } else { hg0 = games[0]; hg1 = games[1]; }
         {
             const bf16x8 a0 = frag_ptr(hblob, OFF_HF, lane)[0], a1 = frag_ptr(hblob, OFF_HF, lane)[64];
 #pragma unroll 1
@@ -356,7 +360,7 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
                 for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
                 acc = MFMA(a0, *reinterpret_cast<const bf16x8*>(base), acc);
                 acc = MFMA(a1, *reinterpret_cast<const bf16x8*>(base + 32), acc);
-                const int y = o >> 3, x = o & 7, bl = b - 2 * wave;
+                const int y = o >> 3, x = o & 7, bl = b - 2 * wave + 2 * half;
                 if (h == 0 && x != 7) {
                     const int cell = y * 7 + x;
                     hp[bl * 96 + cell] = (__bf16)fmaxf(acc[0] + sbias[96], 0.0f);
@@ -365,7 +369,11 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
                 }
             }
         }
-        const int bcol = lane & 1;             // MFMA columns 2..31 duplicate the two boards and are ignored
+        // The fully connected heads run once per two tasks (four boards): their weights come from L2
+        // every time, and an MFMA has 32 columns to fill.
+        const bool last = iter + 1 == MAXIT || mylist[2 * iter + 2] < 0;
+        if (half == 0 && !last) continue;
+        const int bcol = lane & 3;             // MFMA columns 4..31 duplicate the four boards and are ignored
         // ---- value head: FC 42->256 (+ReLU) as 8 row tiles, then 256->1 and tanh
         {
             float part = 0.0f;
@@ -389,37 +397,45 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
                 }
             }
             part += __shfl_xor(part, 32);
-            if (lane < 2 && games[lane] >= 0)
-                v_out[games[lane]] = tanhf(part + reinterpret_cast<const float*>(hblob + OFF_B2)[0]);
+            const int vg = lane == 0 ? hg0 : lane == 1 ? hg1 : lane == 2 ? hg2 : lane == 3 ? hg3 : -1;
+            if (vg >= 0) v_out[vg] = tanhf(part + reinterpret_cast<const float*>(hblob + OFF_B2)[0]);
         }
-        // ---- policy head: FC 84->42 as 2 row tiles (cells 0..31, 32..41)
-#pragma unroll 1
-        for (int t = 0; t < 2; ++t) {
-            f32x16 acc;
+        // ---- policy head: FC 84->42 as 2 row tiles (cells 0..31, 32..41).  The logits overwrite the
+        // head planes, so both tiles are accumulated before the first store.
+        {
+            f32x16 pacc[2];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+            for (int t = 0; t < 2; ++t) {
 #pragma unroll
-            for (int s = 0; s < 6; ++s) {
-                const bf16x8 a = frag_ptr(hblob, OFF_PF + (t * 6 + s) * 1024, lane)[0];
-                const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(hp + bcol * 96 + 16 * s + 8 * h);
-                acc = MFMA(a, bfr, acc);
-            }
-            if ((lane & 31) < 2) {
+                for (int i = 0; i < 16; ++i) pacc[t][i] = 0.0f;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 bp = *reinterpret_cast<const f32x4*>(sbp + 32 * t + 8 * g + 4 * h);
-                    f32x4 o4;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) o4[i] = acc[4 * g + i] + bp[i];
-                    *reinterpret_cast<f32x4*>(lg + bcol * 64 + 32 * t + 8 * g + 4 * h) = o4;
+                for (int s = 0; s < 6; ++s) {
+                    const bf16x8 a = frag_ptr(hblob, OFF_PF + (t * 6 + s) * 1024, lane)[0];
+                    const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(hp + bcol * 96 + 16 * s + 8 * h);
+                    pacc[t] = MFMA(a, bfr, pacc[t]);
                 }
             }
+            if ((lane & 31) < 4) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 bp = *reinterpret_cast<const f32x4*>(sbp + 32 * t + 8 * g + 4 * h);
+                        f32x4 o4;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o4[i] = pacc[t][4 * g + i] + bp[i];
+                        *reinterpret_cast<f32x4*>(lg + bcol * 64 + 32 * t + 8 * g + 4 * h) = o4;
+                    }
+            }
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // lg written by lanes 0,1,32,33, read below
-        if (lane < 16) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // lg written by lanes 0..3 and 32..35, read below
+        float pr = 0.0f;
+        int gidx = -1, c = 0;
+        if (lane < 32) {
             // landing-cell gather (connectfour.py:56-71) + soft-max over legal columns (mcts.py:106)
-            const int b = lane >> 3, c = lane & 7;
-            const int gidx = games[b];
+            const int b = lane >> 3;
+            c = lane & 7;
+            gidx = b == 0 ? hg0 : b == 1 ? hg1 : b == 2 ? hg2 : hg3;
             uint64_t occ = 0;
             if (gidx >= 0) occ = leaf_bb[2 * (size_t)gidx] | leaf_bb[2 * (size_t)gidx + 1];
             const int height = c < 7 ? __popcll((occ >> (7 * c)) & 0x3Full) : 6;
@@ -430,8 +446,13 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
             const float e = legal ? __expf(logit - m) : 0.0f;
             float sum = e;
             sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
-            if (c < 7 && gidx >= 0) p_out[(size_t)gidx * 7 + c] = legal ? e / sum : 0.0f;
+            pr = legal ? e / sum : 0.0f;
         }
+        if (lane < 32 && c < 7 && gidx >= 0) p_out[(size_t)gidx * 7 + c] = pr;
+        // the planes' k-padding (cells 42..47 and 84..95) must read as zero again for the next pass
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        for (int i = lane; i < PW_BYTES / 4; i += 64) reinterpret_cast<uint32_t*>(pw)[i] = 0u;
+        hg0 = hg1 = hg2 = hg3 = -1;
     }
 }
 

@@ -124,6 +124,10 @@ def main():
     ap.add_argument('--preroll', type=int, default=24,
                     help='untimed lock-step moves played before warmup so that the game slots are spread '
                          'over opening / middle game / endgame as in a long-running job')
+    ap.add_argument('--mix-moves', type=int, default=160,
+                    help='untimed lock-step moves with the in-kernel uniform prior played first: all slots start '
+                         'at move 0, and only after several game lengths are their ages spread the way a '
+                         'long-running job has them (cheap: ~12 ms per move)')
     ap.add_argument('--node-capacity', type=int, default=0, help='nodes per game pool (0 = never-free bound)')
     ap.add_argument('--allow-pool-errors', action='store_true', help='tuning only')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -206,6 +210,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    for i in range(args.mix_moves):
+        eng.begin_move_uniform()
+        eng.run_sims_uniform(S)
+        eng.choose_and_advance()
+        if i % 2 == 1:
+            eng.drain_finished()
     for i in range(args.preroll):
         one_step(False)
         if i % 2 == 1:
@@ -245,29 +255,45 @@ def main():
         'dtype': 'f64 PUCT score, f32 W/P, u32 N' + ('' if net is None else '; net trunk bf16 MFMA, f32 accumulate'),
         'data': 'synthetic',
         'config': {'workload': f'connect4 self-play, {S} sims/move, {G} games/GPU, exploration_depth 4, '
-                               f'reuse_search_tree, model {args.model}, {args.preroll} pre-roll moves',
+                               f'reuse_search_tree, model {args.model}, {args.mix_moves} age-mixing moves + '
+                               f'{args.preroll} pre-roll moves',
                    'games_per_gpu': G, 'sims_per_move': S, 'net': args.model,
                    'net_impl': None if net is None else args.net_impl, 'preroll_moves': args.preroll,
+                   'mix_moves': args.mix_moves,
                    'mean_select_depth': d, 'leaf_eval_fraction': f,
                    'games_finished': st1['games'] - st0['games']},
     }
     if rank == 0:
         def avg_ms(pairs):
             return sum(a.elapsed_time(b) for a, b in pairs) / len(pairs)
+
+        def pmc_traffic(kernel_prefix):
+            """HBM bytes per launch from the committed counter passes of this same command
+            (profiles/r01_pmc_means.json: FETCH_SIZE and WRITE_SIZE in KiB, separate passes;
+            FETCH_SIZE doubled, the gfx950 correction for 16-byte-per-lane reads)."""
+            try:
+                pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_means.json')))
+                fe = [v['FETCH_SIZE']['mean'] for k, v in pm['pmc_fetch'].items() if k.startswith(kernel_prefix)]
+                wr = [v['WRITE_SIZE']['mean'] for k, v in pm['pmc_write'].items() if k.startswith(kernel_prefix)]
+                return (2.0 * fe[0] + wr[0]) * 1024.0
+            except (OSError, KeyError, IndexError, ValueError):
+                return None
         bps = bytes_per_sim(d, f)
         if net is not None and args.net_impl == 'hip':
             ms = avg_ms(net_ev)
             fl = trunk_flops_per_leaf(6, 32) * f * G          # leaves one launch evaluates x flops per leaf
             tf = fl / (ms * 1e-3) / 1e12
             out['roofline'] = {'kernel': 'k_c4net_bf16', 'bound': 'mfma', 'achieved': tf, 'peak': BF16_PEAK_TFLOPS,
-                               'unit': 'TFLOP/s', 'frac': tf / BF16_PEAK_TFLOPS, 'traffic': None,
+                               'unit': 'TFLOP/s', 'frac': tf / BF16_PEAK_TFLOPS, 'traffic': pmc_traffic('k_c4net_bf16'),
                                'avg_launch_ms': ms, 'flops_per_leaf': trunk_flops_per_leaf(6, 32),
                                'leaves_per_launch': f * G}
             ms = avg_ms(tree_ev)
             gbs = bps * G / (ms * 1e-3) / 1e9
             out['roofline_tree'] = {'kernel': 'k_sim_step<GameC4,true,true>', 'bound': 'hbm', 'achieved': gbs,
                                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
-                                    'traffic': None, 'avg_launch_ms': ms, 'bytes_per_sim': bps}
+                                    'traffic': pmc_traffic('void k_sim_step_p<GameC4, 8, true, true>'),
+                                    'algorithmic_bytes_per_launch': bps * G,
+                                    'avg_launch_ms': ms, 'bytes_per_sim': bps}
         elif net is None:
             ms = avg_ms(tree_ev)
             gbs = bps * G * S / (ms * 1e-3) / 1e9

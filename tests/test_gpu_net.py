@@ -31,7 +31,10 @@ def _randomize_bn(m, seed):
             mod.bias.data.uniform_(-0.2, 0.2, generator=g)
 
 
-@pytest.mark.parametrize('blocks,ch,n', [(6, 32, 1000), (2, 8, 37), (1, 32, 16), (3, 16, 512)])
+# the larger sizes give every wave several leaves (tasks of two boards, heads run per four boards,
+# a trailing single-board task), the small ones leave most waves idle
+@pytest.mark.parametrize('blocks,ch,n', [(6, 32, 1000), (2, 8, 37), (1, 32, 16), (3, 16, 512), (1, 32, 9001),
+                                         (2, 16, 6150), (1, 8, 14337)])
 def test_fused_bf16_forward_matches_torch_fp32(blocks, ch, n):
     from alphazero_amd import engine as E
     from alphazero_amd.models import AlphaZeroC4
@@ -39,7 +42,8 @@ def test_fused_bf16_forward_matches_torch_fp32(blocks, ch, n):
     torch.manual_seed(blocks * 100 + ch)
     model = AlphaZeroC4(blocks, ch).eval()
     _randomize_bn(model, 5)
-    hists = _random_positions(n, 11)
+    base = _random_positions(min(n, 1200), 11)
+    hists = [base[(i * 7) % len(base)] for i in range(n)]
     bb, nm = E.positions_from_history(1, hists)
     legal, _, _ = E.game_query(1, bb, nm)
     info = ((legal << 16) | 1).to(torch.int32)
@@ -70,8 +74,9 @@ def test_fused_forward_packs_only_leaves_that_need_eval():
     from alphazero_amd.net import FusedC4Net
     torch.manual_seed(3)
     model = AlphaZeroC4(2, 32).eval()
-    n = 3000
-    hists = _random_positions(n, 21)
+    n = 11000
+    base = _random_positions(1500, 21)
+    hists = [base[(i * 11) % len(base)] for i in range(n)]
     bb, nm = E.positions_from_history(1, hists)
     legal, _, _ = E.game_query(1, bb, nm)
     net = FusedC4Net.from_module(model, 'cuda')
