@@ -48,9 +48,54 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // rows of the activation tensor: whole workgroups of GB boards
 __host__ __device__ static inline size_t act_positions(int n) { return (size_t)((n + GB - 1) / GB * GB) * BPOS; }
 
+// ---- which leaves need the network: list[rank] = leaf index, in leaf order --------------------
+// One workgroup; thread t takes `per` consecutive leaves, a shuffle scan per wave and one pass over
+// the 16 wave totals give every thread its first rank.  list[n] receives the count.
+__global__ void __launch_bounds__(1024) k_compact128(const int32_t* __restrict__ leaf_info, int n, int32_t* __restrict__ list) {
+    __shared__ int wtot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (n + 1023) / 1024, g0 = tid * per;
+    unsigned long long mask = 0;                       // per <= 32 (n <= 32768)
+    for (int j = 0; j < per; ++j) {
+        const int g = g0 + j;
+        if (g < n) {
+            const int k = leaf_info[g] & 0xFF;
+            if (k == AZ_LEAF_EVAL || k == AZ_LEAF_ROOT) mask |= 1ull << j;
+        }
+    }
+    const int cnt = __popcll(mask);
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const int t = wtot[w];
+        before += (w < wave) ? t : 0;
+        total += t;
+    }
+    int rank = before + incl - cnt;
+    while (mask) {
+        const int j = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        list[rank++] = g0 + j;
+    }
+    if (tid == 0) list[n] = total;
+}
+
+// number of boards to evaluate and the leaf behind board b (list == nullptr: every leaf, in order)
+__device__ __forceinline__ int boards_to_run(const int32_t* list, int n) { return list ? list[n] : n; }
+__device__ __forceinline__ long leaf_of(const int32_t* list, long b) { return list ? (long)list[b] : b; }
+
 // ---- stem: 2 -> 128 channels straight from the bitboards (vector ALU, fp32 accumulate) ----------
 __global__ void __launch_bounds__(256) k_stem128(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ leaf_bb,
-                                                 int n, __bf16* __restrict__ out) {
+                                                 const int32_t* __restrict__ list, int nleaves, __bf16* __restrict__ out) {
+    const int n = boards_to_run(list, nleaves);
     __shared__ float w[18 * CH];
     __shared__ float bias[CH];
     for (int i = threadIdx.x; i < 18 * CH; i += 256) w[i] = reinterpret_cast<const float*>(blob + G_STEM)[i];
@@ -73,7 +118,8 @@ __global__ void __launch_bounds__(256) k_stem128(const uint8_t* __restrict__ blo
     }
     // bit of cell (row, column) is 7*column + row; shifted by 8 so that the 3x3 window never indexes
     // below bit 0, and row 6 / column 7 land on bits that are always clear
-    const uint64_t bb0 = leaf_bb[2 * b] << 8, bb1 = leaf_bb[2 * b + 1] << 8;
+    const long leaf = leaf_of(list, b);
+    const uint64_t bb0 = leaf_bb[2 * leaf] << 8, bb1 = leaf_bb[2 * leaf + 1] << 8;
     float acc[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) acc[c] = bias[cg * 16 + c];
@@ -236,8 +282,9 @@ __device__ __forceinline__ void tower_tap(f32x16 (&acc)[NTILE], const uint4 (&cu
 
 __global__ void __launch_bounds__(NT, 2)
 k_tower128(const uint8_t* __restrict__ wts /* fragment order, two convs */, const float* __restrict__ bias /* [3][128] */,
-           __bf16* __restrict__ act, int num_blocks) {
+           __bf16* __restrict__ act, int num_blocks, const int32_t* __restrict__ list, int nleaves) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // [2][SLAB_ROWS][ROWB], then f32 [2][128] biases
+    if ((int)blockIdx.x * GB >= boards_to_run(list, nleaves)) return;   // whole workgroup, before any barrier
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 31;
     const int wp = wave >> 2;
     TowerCtx c;
@@ -323,8 +370,10 @@ k_tower128(const uint8_t* __restrict__ wts /* fragment order, two convs */, cons
 // ---- heads: 1x1 convs, FCs, landing-cell gather, soft-max (vector ALU, fp32) ---------------------
 #define HB_ 8
 __global__ void __launch_bounds__(256) k_heads128(const uint8_t* __restrict__ blob, const __bf16* __restrict__ act,
-                                                  const uint64_t* __restrict__ leaf_bb, int n, float* __restrict__ p_out,
-                                                  float* __restrict__ v_out) {
+                                                  const uint64_t* __restrict__ leaf_bb, const int32_t* __restrict__ list,
+                                                  int nleaves, float* __restrict__ p_out, float* __restrict__ v_out) {
+    const int n = boards_to_run(list, nleaves);
+    if ((long)blockIdx.x * HB_ >= n) return;
     __shared__ float hpv[HB_ * 3 * 42];
     __shared__ float hid[256 * HB_];
     const int tid = threadIdx.x;
@@ -371,9 +420,10 @@ __global__ void __launch_bounds__(256) k_heads128(const uint8_t* __restrict__ bl
     __syncthreads();
     if (tid < HB_ * 8) {
         const int b = tid >> 3, c = tid & 7;
-        const long gidx = board0 + b;
+        const bool live = board0 + b < n;
+        const long gidx = live ? leaf_of(list, board0 + b) : 0;
         uint64_t occ = 0;
-        if (gidx < n) occ = leaf_bb[2 * gidx] | leaf_bb[2 * gidx + 1];
+        if (live) occ = leaf_bb[2 * gidx] | leaf_bb[2 * gidx + 1];
         const int height = c < 7 ? __popcll((occ >> (7 * c)) & 0x3Full) : 6;
         const bool legal = c < 7 && height < 6;
         float logit = -INFINITY;
@@ -389,13 +439,12 @@ __global__ void __launch_bounds__(256) k_heads128(const uint8_t* __restrict__ bl
         const float e = legal ? __expf(logit - m) : 0.0f;
         float sum = e;
         sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
-        if (c < 7 && gidx < n) p_out[(size_t)gidx * 7 + c] = legal ? e / sum : 0.0f;
+        if (c < 7 && live) p_out[(size_t)gidx * 7 + c] = legal ? e / sum : 0.0f;
     } else if (tid >= 128 && tid < 128 + HB_) {
         const int b = tid - 128;
-        const long gidx = board0 + b;
         float s = 0.0f;
         for (int u = 0; u < 256; ++u) s += hid[u * HB_ + b];
-        if (gidx < n) v_out[gidx] = tanhf(s + reinterpret_cast<const float*>(blob + G_B2)[0]);
+        if (board0 + b < n) v_out[leaf_of(list, board0 + b)] = tanhf(s + reinterpret_cast<const float*>(blob + G_B2)[0]);
     }
 }
 
@@ -403,15 +452,19 @@ extern "C" {
 
 int az_c4net128_blob_bytes(void) { return G_BLOB_BYTES; }
 
-// one activation tensor, padded to whole workgroups of boards
-long az_c4net128_workspace_bytes(int32_t n) { return n < 0 ? -1 : (long)(act_positions(n) * CH * 2); }
+// one activation tensor, padded to whole workgroups of boards, then the list of leaves to evaluate
+static size_t act_bytes(int32_t n) { return (act_positions(n) * CH * 2 + 255) / 256 * 256; }
+long az_c4net128_workspace_bytes(int32_t n) { return n < 0 ? -1 : (long)(act_bytes(n) + ((size_t)n + 1) * 4); }
 
-int az_c4net128_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uint64_t* leaf_bb, int32_t n,
-                             void* workspace, float* p, float* v, void* stream) {
+int az_c4net128_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uint64_t* leaf_bb,
+                             const int32_t* leaf_info, int32_t n, void* workspace, float* p, float* v, void* stream) {
     if (n < 0 || num_blocks < 0 || (n && (!blob || !leaf_bb || !workspace || !p || !v))) return -1;
     if (n == 0) return 0;
+    if (leaf_info && n > 32768) return -4;              // k_compact128 keeps 32 flags per thread
     hipStream_t st = (hipStream_t)stream;
     __bf16* t0 = reinterpret_cast<__bf16*>(workspace);
+    int32_t* list = leaf_info ? reinterpret_cast<int32_t*>(static_cast<uint8_t*>(workspace) + act_bytes(n)) : nullptr;
+    if (list) hipLaunchKernelGGL(k_compact128, dim3(1), dim3(1024), 0, st, leaf_info, (int)n, list);
     const int lds = BIAS_OFF + 2 * CH * 4;
     static bool attr_set = false;
     if (!attr_set) {
@@ -422,11 +475,15 @@ int az_c4net128_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uint
     }
     const int ngroups = (n + GB - 1) / GB;
     const long stem_threads = (long)act_positions(n) * 8;
-    hipLaunchKernelGGL(k_stem128, dim3((unsigned)((stem_threads + 255) / 256)), dim3(256), 0, st, blob, leaf_bb, (int)n, t0);
+    // grids cover all n leaves; workgroups past the compacted count leave at once
+    hipLaunchKernelGGL(k_stem128, dim3((unsigned)((stem_threads + 255) / 256)), dim3(256), 0, st, blob, leaf_bb,
+                       (const int32_t*)list, (int)n, t0);
     const float* bias = reinterpret_cast<const float*>(blob + G_BIAS);
     if (num_blocks > 0)
-        hipLaunchKernelGGL(k_tower128, dim3(ngroups), dim3(NT), lds, st, blob + G_W, bias, t0, (int)num_blocks);
-    hipLaunchKernelGGL(k_heads128, dim3((n + HB_ - 1) / HB_), dim3(256), 0, st, blob, t0, leaf_bb, (int)n, p, v);
+        hipLaunchKernelGGL(k_tower128, dim3(ngroups), dim3(NT), lds, st, blob + G_W, bias, t0, (int)num_blocks,
+                           (const int32_t*)list, (int)n);
+    hipLaunchKernelGGL(k_heads128, dim3((n + HB_ - 1) / HB_), dim3(256), 0, st, blob, t0, leaf_bb, (const int32_t*)list,
+                       (int)n, p, v);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

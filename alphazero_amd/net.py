@@ -259,6 +259,6 @@ class C4Net128:
             self._p = torch.empty(n, 7, dtype=torch.float32, device=self.device)
             self._v = torch.empty(n, dtype=torch.float32, device=self.device)
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        check(self.lib.az_c4net128_bf16_forward(ptr(self.blob), self.num_blocks, ptr(leaf_bb), n,
+        check(self.lib.az_c4net128_bf16_forward(ptr(self.blob), self.num_blocks, ptr(leaf_bb), ptr(leaf_info), n,
                                                 ptr(self.workspace), ptr(self._p), ptr(self._v), st))
         return self._p, self._v

@@ -47,11 +47,14 @@ class SelfPlayWorker:
         self._evaluator = evaluator           # callable(leaf_bb, leaf_info) -> (p, v); None = built-in
         self._fused = None
         if evaluator is None:
-            # Connect Four nets with <= 32 trunk channels run in the fused HIP kernel
+            # Connect Four nets run in hand-written HIP kernels: up to 32 trunk channels in the
+            # one-launch fused kernel, 128 channels in the stem / tower / heads kernels
             from .models import AlphaZeroC4
-            from .net import CMAX, FusedC4Net
+            from .net import CMAX, C4Net128, FusedC4Net
             if isinstance(self._model, AlphaZeroC4) and self._model.block_channels <= CMAX:
                 self._fused = FusedC4Net.from_module(self._model, self._device)
+            elif isinstance(self._model, AlphaZeroC4) and self._model.block_channels == 128:
+                self._fused = C4Net128(self._model, self._device, max_leaves=self.num_games)
         self._version = 0
         self.positions = 0
         self.games_finished = 0

@@ -117,7 +117,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=6)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--model', default='c4_6x32', choices=['uniform', 'c4_6x32'])
+    ap.add_argument('--model', default='c4_6x32', choices=['uniform', 'c4_6x32', 'c4_10x128'])
     ap.add_argument('--net-impl', default='hip', choices=['torch', 'hip'])
     ap.add_argument('--games', type=int, default=8192)
     ap.add_argument('--sims', type=int, default=800)
@@ -158,13 +158,14 @@ def main():
     if args.model != 'uniform':
         from alphazero_amd.models import AlphaZeroC4
         from alphazero_amd.mcts import evaluate_leaves
-        blocks, ch = 6, 32                      # alphazero/config/connectfour.yaml:4-9
+        # alphazero/config/connectfour.yaml:4-9 ships 6x32; 10x128 is the larger leaf-eval configuration
+        blocks, ch = (6, 32) if args.model == 'c4_6x32' else (10, 128)
         torch.manual_seed(0)
         net = AlphaZeroC4(blocks, ch).to(dev).eval()
         from alphazero_amd.distributed import broadcast_model
         if args.net_impl == 'hip':
-            from alphazero_amd.net import FusedC4Net
-            fused = FusedC4Net.from_module(net, dev)
+            from alphazero_amd.net import C4Net128, FusedC4Net
+            fused = FusedC4Net.from_module(net, dev) if ch <= 32 else C4Net128(net, dev, max_leaves=G)
             evaluate = lambda bb, info: fused(bb, info)
         else:
             evaluate = lambda bb, info: evaluate_leaves(eng.game, net, bb, info)
@@ -281,11 +282,15 @@ def main():
         bps = bytes_per_sim(d, f)
         if net is not None and args.net_impl == 'hip':
             ms = avg_ms(net_ev)
-            fl = trunk_flops_per_leaf(6, 32) * f * G          # leaves one launch evaluates x flops per leaf
+            # leaves one launch evaluates x flops per leaf; the 128-channel kernels take every leaf of
+            # the batch, needed or not, and only the needed ones count as algorithmic work
+            fl = trunk_flops_per_leaf(blocks, ch) * f * G
             tf = fl / (ms * 1e-3) / 1e12
-            out['roofline'] = {'kernel': 'k_c4net_bf16', 'bound': 'mfma', 'achieved': tf, 'peak': BF16_PEAK_TFLOPS,
-                               'unit': 'TFLOP/s', 'frac': tf / BF16_PEAK_TFLOPS, 'traffic': pmc_traffic('k_c4net_bf16'),
-                               'avg_launch_ms': ms, 'flops_per_leaf': trunk_flops_per_leaf(6, 32),
+            kname = 'k_c4net_bf16' if ch <= 32 else 'k_stem128 + k_tower128 + k_heads128'
+            out['roofline'] = {'kernel': kname, 'bound': 'mfma', 'achieved': tf, 'peak': BF16_PEAK_TFLOPS,
+                               'unit': 'TFLOP/s', 'frac': tf / BF16_PEAK_TFLOPS,
+                               'traffic': pmc_traffic('k_c4net_bf16') if ch <= 32 else None,
+                               'avg_launch_ms': ms, 'flops_per_leaf': trunk_flops_per_leaf(blocks, ch),
                                'leaves_per_launch': f * G}
             ms = avg_ms(tree_ev)
             gbs = bps * G / (ms * 1e-3) / 1e9

@@ -195,14 +195,18 @@ int  az_c4net_f32_blob_floats(void);
 int  az_c4net_f32_forward(const float* blob, int32_t num_blocks, const uint64_t* leaf_bb, int32_t n,
                           float* p, float* v, void* stream);
 
-/* 128-channel trunk (e.g. the 10x128 network): one launch per conv, bf16 activations in a caller
- * workspace of az_c4net128_workspace_bytes(n) bytes that must be ZERO-FILLED ONCE before its first
- * use (its zero rows/columns are never written).  blob = az_c4net128_blob_bytes() bytes packed by
- * alphazero_amd/net.py pack_c4_blob_128.  Evaluates every one of the n leaves.                 */
+/* 128-channel network (e.g. 10x128) on bf16 MFMA: stem, residual tower with LDS-resident
+ * activations, heads -- three launches, plus one that lists the leaves to evaluate when leaf_info is
+ * given (kinds EVAL / ROOT, as az_c4net_bf16_forward; NULL = every leaf).  workspace = DEVICE buffer
+ * of az_c4net128_workspace_bytes(n) bytes (contents need not be preserved between calls), blob =
+ * az_c4net128_blob_bytes() bytes packed by alphazero_amd/net.py pack_c4_blob_128.  Rows of p / v
+ * whose leaf is not evaluated are left untouched.  n <= 32768 when leaf_info is given.
+ * Replaces the same reference lines as az_c4net_bf16_forward.                                   */
 int  az_c4net128_blob_bytes(void);
 long az_c4net128_workspace_bytes(int32_t n);
-int  az_c4net128_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uint64_t* leaf_bb, int32_t n,
-                              void* workspace, float* p, float* v, void* stream);
+int  az_c4net128_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uint64_t* leaf_bb,
+                              const int32_t* leaf_info, int32_t n, void* workspace, float* p, float* v,
+                              void* stream);
 
 #ifdef __cplusplus
 }

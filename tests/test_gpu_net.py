@@ -152,3 +152,32 @@ def test_trunk128_bf16_matches_torch_fp32(blocks, n):
     assert torch.all(p[~valid] == 0)
     # bf16 activations and weights through 2*blocks+1 convs of K = 1152: 2e-2 absolute on p, v
     assert dp < 2e-2 and dv < 2e-2
+
+
+def test_trunk128_evaluates_only_leaves_that_need_it():
+    """With leaf_info the 128-channel path lists the EVAL / ROOT leaves first and runs only those; their
+    rows equal the dense evaluation bit for bit, the other rows are left alone."""
+    from alphazero_amd import engine as E
+    from alphazero_amd.models import AlphaZeroC4
+    from alphazero_amd.net import C4Net128
+    torch.manual_seed(9)
+    model = AlphaZeroC4(1, 128).eval()
+    n = 2500
+    base = _random_positions(600, 31)
+    hists = [base[(i * 5) % len(base)] for i in range(n)]
+    bb, nm = E.positions_from_history(1, hists)
+    legal, _, _ = E.game_query(1, bb, nm)
+    net = C4Net128(model, 'cuda', max_leaves=n)
+    dense_p, dense_v = net(bb)
+    dense_p, dense_v = dense_p.clone(), dense_v.clone()
+    rng = np.random.RandomState(6)
+    for frac in (0.0, 0.01, 0.6, 1.0):
+        kind = torch.from_numpy(rng.choice([0, 1, 2, 3], size=n, p=[(1 - frac) / 2, frac * 0.9, (1 - frac) / 2, frac * 0.1])
+                                .astype(np.int32)).cuda()
+        info = ((legal << 16) | kind).to(torch.int32)
+        net._p.fill_(-7.0)
+        net._v.fill_(-7.0)
+        p, v = net(bb, info)
+        act = (kind == 1) | (kind == 3)
+        assert torch.equal(p[act], dense_p[act]) and torch.equal(v[act], dense_v[act])
+        assert torch.all(p[~act] == -7.0) and torch.all(v[~act] == -7.0)

@@ -83,3 +83,20 @@ def test_c4_net_fused_and_torch_paths():
         assert all(v == 7 for _, v in ds.games)
         assert len({tuple(g.history) for g, _ in ds.games}) > 10     # device RNG: games differ
         assert w.engine.stats()['errors'] == 0
+
+
+def test_c4_net_128_channels_uses_the_tower_kernel():
+    from alphazero_amd.models import AlphaZeroC4
+    from alphazero_amd.net import C4Net128
+    from alphazero_amd.selfplay import SelfPlayWorker
+    model = {'module': 'alphazero.games.connectfour', 'name': 'AlphaZeroC4',
+             'kwargs': {'num_blocks': 2, 'channels_per_block': 128}}
+    cfg = _config({'module': 'alphazero.games.connectfour', 'name': 'ConnectFour'}, model, S=16)
+    torch.manual_seed(0)
+    ds, srv = _Dataset(), _Server(3, AlphaZeroC4(2, 128).state_dict())
+    w = SelfPlayWorker(cfg, srv, ds, 'cuda', num_games=40, seed=5)
+    assert isinstance(w._fused, C4Net128)
+    while len(ds.games) < 20:
+        assert w.play_game() == 3
+    _check_games(ds, orc.C4, 16, True)
+    assert w.engine.stats()['errors'] == 0
