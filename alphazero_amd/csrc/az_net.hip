@@ -57,7 +57,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define MAXIT 8                               // wave-tasks per wave per launch (n <= 32768)
 #define S_TL (S_PW + 8 * PW_BYTES)            // int [8 waves][MAXIT][2] leaf index of each board
 #define S_WT (S_TL + 8 * MAXIT * 2 * 4)       // int [16] scan scratch
-#define S_BYTES (S_WT + 64)
+#define S_DUMP (S_WT + 64)                    // 64 B per wave: landing place for results of zero cells
+#define S_BYTES (S_DUMP + 8 * 64)
 #define LDS_BYTES (2 * ACT_BYTES + S_BYTES)
 
 // blob layout (bytes); must match alphazero_amd/net.py
@@ -92,30 +93,40 @@ __device__ __forceinline__ f32x16 bias_acc(const float* bias, int h) {
     return acc;
 }
 
-// (+ residual from dst) -> ReLU -> bf16 -> dst, 4 channels per 8-byte store
+// bf16(ReLU(a)), bf16(ReLU(b)) packed in one dword: convert first, then clamp the two bit patterns
+// as signed 16-bit integers (negative floats, -0 included, are negative integers) -- one
+// v_cvt_pk_bf16_f32 and one v_pk_max_i16 per pair instead of two v_max_f32 per value
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+__device__ __forceinline__ uint32_t relu_bf16x2(float a, float b) {
+    bf16x2 y;
+    y[0] = (__bf16)a; y[1] = (__bf16)b;
+    const s16x2 z = {0, 0};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, y), z));
+}
+
+// (+ residual from q) -> ReLU -> bf16 -> q, 4 channels per 8-byte store; q = the lane's position
+// (channel 0) plus h * 8
 template <bool RES>
-__device__ __forceinline__ void store_tile(const f32x16& acc, uint8_t* dst, int pos, int h) {
+__device__ __forceinline__ void store_tile(const f32x16& acc, uint8_t* q) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        uint8_t* q = dst + pos * PSTRIDE + g * 16 + h * 8;
         float x0 = acc[4 * g], x1 = acc[4 * g + 1], x2 = acc[4 * g + 2], x3 = acc[4 * g + 3];
         if (RES) {
-            const uint2 r = *reinterpret_cast<const uint2*>(q);
+            const uint2 r = *reinterpret_cast<const uint2*>(q + g * 16);
             x0 += __uint_as_float(r.x << 16); x1 += __uint_as_float(r.x & 0xFFFF0000u);
             x2 += __uint_as_float(r.y << 16); x3 += __uint_as_float(r.y & 0xFFFF0000u);
         }
-        bf16x4 y;
-        y[0] = (__bf16)fmaxf(x0, 0.0f); y[1] = (__bf16)fmaxf(x1, 0.0f);
-        y[2] = (__bf16)fmaxf(x2, 0.0f); y[3] = (__bf16)fmaxf(x3, 0.0f);
-        *reinterpret_cast<bf16x4*>(q) = y;
+        *reinterpret_cast<uint2*>(q + g * 16) = make_uint2(relu_bf16x2(x0, x1), relu_bf16x2(x2, x3));
     }
 }
 
-// fragments of one row of taps (3 taps x 2 channel halves) for a tile
+// fragments of one row of taps (3 taps x 2 channel halves) for a tile.  `base` points 9 positions
+// before the tile's own position, so every tap is a non-negative immediate offset of the ds_read.
 __device__ __forceinline__ void load_taps(bf16x8 (&f)[6], const uint8_t* base, int row) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const int d = ((row - 1) * 8 + (i - 1)) * PSTRIDE;
+        const int d = (row * 8 + i) * PSTRIDE;
         f[2 * i] = *reinterpret_cast<const bf16x8*>(base + d);
         f[2 * i + 1] = *reinterpret_cast<const bf16x8*>(base + d + 32);
     }
@@ -127,19 +138,19 @@ __device__ __forceinline__ void load_taps(bf16x8 (&f)[6], const uint8_t* base, i
 // never-written zero rows, so the tower needs no workgroup barrier: LDS operations of one wave
 // complete in issue order.  Loads run one row of taps ahead of the MFMAs that consume them.
 template <bool RES>
-__device__ __forceinline__ void conv3x3(const Weights& w, const uint8_t* src, uint8_t* dst, const float* bias,
-                                        int wave, int lane, bool two) {
+__device__ __forceinline__ void conv3x3(const Weights& w, const uint8_t* src, uint8_t* dst, uint8_t* dump,
+                                        const float* bias, int wave, int lane, bool two) {
     const int h = lane >> 5;
-    int pos[TILES_PER_WAVE];
+    int posb[TILES_PER_WAVE];
     bool keep[TILES_PER_WAVE];
     const uint8_t* base[TILES_PER_WAVE];
 #pragma unroll
     for (int t = 0; t < TILES_PER_WAVE; ++t) {
         const int R = (wave * TILES_PER_WAVE + t) * 32 + (lane & 31);
         const int b = R / 48, o = R - b * 48;
-        pos[t] = b * BOARD_POS + POS0 + o;
+        posb[t] = (b * BOARD_POS + POS0 + o) * PSTRIDE;
         keep[t] = (o & 7) != 7;
-        base[t] = src + pos[t] * PSTRIDE + h * 16;
+        base[t] = src + posb[t] + (h * 16 - 9 * PSTRIDE);
     }
     bf16x8 fa[6], fb[6];
     load_taps(fa, base[0], 0);
@@ -156,7 +167,8 @@ __device__ __forceinline__ void conv3x3(const Weights& w, const uint8_t* src, ui
         if (t + 1 < TILES_PER_WAVE) load_taps(fb, base[t + 1], 0);
 #pragma unroll
         for (int i = 0; i < 6; ++i) acc = MFMA(w.f[12 + i], fa[i], acc);
-        if (keep[t]) store_tile<RES>(acc, dst, pos[t], h);
+        // the zero cell that closes each row is computed like a cell; its result goes to a dump row
+        store_tile<RES>(acc, (keep[t] ? dst + posb[t] : dump) + h * 8);
         if (t + 1 < TILES_PER_WAVE) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) fa[i] = fb[i];
@@ -203,7 +215,7 @@ __device__ __forceinline__ void stem(const uint8_t* blob, const uint64_t* leaf_b
         f32x16 acc = bias_acc(bias, h);
         acc = MFMA(a0, f[0], acc);
         acc = MFMA(a1, f[1], acc);
-        if (x != 7) store_tile<false>(acc, dst, pos, h);
+        if (x != 7) store_tile<false>(acc, dst + pos * PSTRIDE + h * 8);
     }
 }
 
@@ -324,6 +336,7 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
     const float* sw2 = reinterpret_cast<const float*>(scr + S_W2);
     const float* sbp = reinterpret_cast<const float*>(scr + S_BP);
     const int* mylist = tlist + wave * MAXIT * 2;
+    uint8_t* dump = scr + S_DUMP + wave * 64;  // where results for the rows' zero cells go (never read back)
 
     int hg0 = -1, hg1 = -1, hg2 = -1, hg3 = -1;   // leaves whose head planes wait in hp / hv (boards 0..3)
     for (int iter = 0; iter < MAXIT; ++iter) {
@@ -335,8 +348,8 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
         asm volatile("" : "+s"(sblob));
         stem(sblob, leaf_bb, games, bufY, sbias, wave, lane, ntiles);
         for (int blk = 0; blk < num_blocks; ++blk) {
-            conv3x3<false>(w1, bufY, bufX, sbias + 32, wave, lane, two);
-            conv3x3<true>(w2, bufX, bufY, sbias + 64, wave, lane, two);
+            conv3x3<false>(w1, bufY, bufX, dump, sbias + 32, wave, lane, two);
+            conv3x3<true>(w2, bufX, bufY, dump, sbias + 64, wave, lane, two);
         }
 
         // Head weights are fetched here, per task: hoisted above the loop they would be spilled to

@@ -45,6 +45,17 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
+// bf16(ReLU(a)), bf16(ReLU(b)) packed in one dword: convert first, then clamp the two bit patterns
+// as signed 16-bit integers (negative floats, -0 included, are negative integers)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+__device__ __forceinline__ uint32_t relu_bf16x2(float a, float b) {
+    bf16x2 y;
+    y[0] = (__bf16)a; y[1] = (__bf16)b;
+    const s16x2 z = {0, 0};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, y), z));
+}
+
 // rows of the activation tensor: whole workgroups of GB boards
 __host__ __device__ static inline size_t act_positions(int n) { return (size_t)((n + GB - 1) / GB * GB) * BPOS; }
 
@@ -265,10 +276,7 @@ __device__ __forceinline__ void tower_tap(f32x16 (&acc)[NTILE], const uint4 (&cu
                 x0 += __uint_as_float(r[t][gq].x << 16); x1 += __uint_as_float(r[t][gq].x & 0xFFFF0000u);
                 x2 += __uint_as_float(r[t][gq].y << 16); x3 += __uint_as_float(r[t][gq].y & 0xFFFF0000u);
             }
-            bf16x4 y;
-            y[0] = (__bf16)__builtin_amdgcn_fmed3f(x0, 0.0f, INFINITY); y[1] = (__bf16)__builtin_amdgcn_fmed3f(x1, 0.0f, INFINITY);
-            y[2] = (__bf16)__builtin_amdgcn_fmed3f(x2, 0.0f, INFINITY); y[3] = (__bf16)__builtin_amdgcn_fmed3f(x3, 0.0f, INFINITY);
-            *reinterpret_cast<bf16x4*>(dst + c.qrow[t] + 16 * gq) = y;
+            *reinterpret_cast<uint2*>(dst + c.qrow[t] + 16 * gq) = make_uint2(relu_bf16x2(x0, x1), relu_bf16x2(x2, x3));
         }
     }
     __syncthreads();
