@@ -62,24 +62,29 @@ def bytes_to_records(arr):
     return [GameRecord.from_buffer_copy(arr[i].tobytes()) for i in range(arr.shape[0])]
 
 
-def gather_records(records, dst=0, device=None, group=None):
-    """Finished games of every rank collected on `dst` (list of az_game_record there, [] elsewhere).
-    Fixed-size records, one count exchange + one padded all_gather: a few MB per generation."""
+def gather_record_bytes(raw, dst=0, device=None, group=None):
+    """Finished games of every rank collected on `dst`, in the raw form of
+    SelfPlayEngine.drain_finished_bytes: uint8 [n, RECORD_BYTES] in, uint8 [sum n, RECORD_BYTES] out on
+    `dst` (rank order), an empty array elsewhere.  Fixed-size records, one count exchange + one padded
+    all_gather; nothing is parsed on the way."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     device = device or ('cuda' if dist.get_backend(group) == 'nccl' else 'cpu')
-    mine = torch.from_numpy(records_to_bytes(records)).to(device)
-    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(counts, torch.tensor([mine.shape[0]], dtype=torch.int64, device=device), group=group)
-    counts = [int(c.item()) for c in counts]
+    mine = torch.from_numpy(np.ascontiguousarray(raw, np.uint8).reshape(-1, RECORD_BYTES)).to(device)
+    parts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(parts, torch.tensor([mine.shape[0]], dtype=torch.int64, device=device), group=group)
+    counts = torch.cat(parts).tolist()                  # one host read for all counts
     cap = max(max(counts), 1)
     padded = torch.zeros(cap, RECORD_BYTES, dtype=torch.uint8, device=device)
     padded[:mine.shape[0]] = mine
-    bufs = [torch.zeros_like(padded) for _ in range(world)]
+    bufs = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(bufs, padded, group=group)
     if rank != dst:
-        return []
-    out = []
-    for r in range(world):
-        out.extend(bytes_to_records(bufs[r][:counts[r]].cpu().numpy()))
-    return out
+        return np.zeros((0, RECORD_BYTES), np.uint8)
+    return np.concatenate([bufs[r][:counts[r]].cpu().numpy() for r in range(world)], axis=0)
+
+
+def gather_records(records, dst=0, device=None, group=None):
+    """gather_record_bytes for lists of az_game_record: list of all ranks' records on `dst`, []
+    elsewhere."""
+    return bytes_to_records(gather_record_bytes(records_to_bytes(records), dst, device, group))

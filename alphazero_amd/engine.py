@@ -60,6 +60,7 @@ class SelfPlayEngine:
             self.out_nedges = torch.zeros(self.G, dtype=torch.int32, device=self.device)
             self.out_visits = torch.zeros(self.G, self.A, dtype=torch.int32, device=self.device)
             self.out_winner = torch.zeros(self.G, dtype=torch.int32, device=self.device)
+        self._drain_buf = None
 
     def close(self):
         if getattr(self, 'h', None):
@@ -129,13 +130,22 @@ class SelfPlayEngine:
         return self.out_action, self.out_nedges, self.out_visits, self.out_winner
 
     # ---- results -----------------------------------------------------------------
+    def drain_finished_bytes(self):
+        """Finished games since the last drain as a uint8 array [n, sizeof(az_game_record)] (a view of
+        a pinned host buffer that the next drain overwrites; synchronises).  The raw form is what
+        travels between ranks (distributed.gather_record_bytes)."""
+        cap = 2 * self.G + 16
+        if self._drain_buf is None:
+            self._drain_buf = torch.empty(cap * C.sizeof(GameRecord), dtype=torch.uint8).pin_memory()
+        n = C.c_int32()
+        check(self.lib.az_drain_finished(self.h, C.cast(self._drain_buf.data_ptr(), C.POINTER(GameRecord)), cap,
+                                         C.byref(n), _stream()))
+        return self._drain_buf.numpy()[:n.value * C.sizeof(GameRecord)].reshape(n.value, C.sizeof(GameRecord))
+
     def drain_finished(self):
         """Finished games since the last drain as a list of GameRecord (synchronises)."""
-        cap = 2 * self.G + 16
-        buf = (GameRecord * cap)()
-        n = C.c_int32()
-        check(self.lib.az_drain_finished(self.h, buf, cap, C.byref(n), _stream()))
-        return [buf[i] for i in range(n.value)]
+        raw = self.drain_finished_bytes()
+        return [GameRecord.from_buffer_copy(raw[i].tobytes()) for i in range(raw.shape[0])]
 
     def stats(self):
         st = Stats()

@@ -12,8 +12,9 @@ are random-initialised (throughput does not depend on their values).
                   [--games G] [--sims S] [--no-cpu-baseline]
 
 Launched by torch.distributed.run for N > 1 (one rank per GPU, RCCL); games shard across
-ranks with no data-path collective (scaling: weak), weights are broadcast from rank 0 once
-per step when a network is in use.  Rank 0 prints one JSON line.
+ranks with no data-path collective (scaling: weak); per step the weights are broadcast from
+rank 0 (when a network is in use) and the finished games' records are gathered on rank 0.
+Rank 0 prints one JSON line.
 """
 import argparse
 import json
@@ -137,6 +138,7 @@ def main():
     import torch
     import torch.distributed as dist
     from alphazero_amd import engine as E
+    from alphazero_amd.distributed import gather_record_bytes
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -205,6 +207,12 @@ def main():
                 else:
                     eng.expand_backup(p, v)
         eng.choose_and_advance()
+        if measure:
+            # finished games leave the device every move (selfplay.py:41) and, with several ranks,
+            # travel to the replay rank as raw records (replaces replay_buffer.py:28-47)
+            raw = eng.drain_finished_bytes()
+            if world > 1:
+                gather_record_bytes(raw, dst=0, device=dev)
 
     def sync_all():
         if world > 1:
