@@ -52,13 +52,13 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define S_PW (S_BP + 256)                     // per-wave head scratch, PW_BYTES each:
 #define PW_HP 0                               //   bf16 [4][96] policy planes, k = ch*42 + cell
 #define PW_HV 768                             //   bf16 [4][48] value plane
-#define PW_LG 0                               //   float [4][64] cell logits, written over the planes
-#define PW_BYTES 1152
+#define PW_BYTES 1152                         // all 8 together are reused as float [32][64] logits + [8][32] value sums
 #define MAXIT 8                               // wave-tasks per wave per launch (n <= 32768)
 #define S_TL (S_PW + 8 * PW_BYTES)            // int [8 waves][MAXIT][2] leaf index of each board
 #define S_WT (S_TL + 8 * MAXIT * 2 * 4)       // int [16] scan scratch
 #define S_DUMP (S_WT + 64)                    // 64 B per wave: landing place for results of zero cells
-#define S_BYTES (S_DUMP + 8 * 64)
+#define S_HG (S_DUMP + 8 * 64)                // int [32] leaf index of each head column
+#define S_BYTES (S_HG + 128)
 #define LDS_BYTES (2 * ACT_BYTES + S_BYTES)
 
 // blob layout (bytes); must match alphazero_amd/net.py
@@ -326,42 +326,52 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
     }
     __syncthreads();
 
-    // ---- from here on every wave is on its own: it takes two leaves at a time through the whole
-    // network inside its two boards of the LDS images and its own head scratch; no workgroup barrier.
+    // ---- Rounds.  In a round every wave takes up to two tasks (two boards each) through stem, tower
+    // and the 1x1 head convs on its own -- its two boards of the LDS images, no workgroup barrier --
+    // and leaves four boards of head planes in its scratch.  The fully connected heads then run once
+    // for the whole workgroup: 8 waves x 4 boards are exactly the 32 columns of an MFMA, wave w owns
+    // rows 32w..32w+31 of the value FC and waves 0, 1 the two row tiles of the policy FC, so each
+    // head weight is fetched from L2 once per workgroup and round instead of once per wave and pass.
     uint8_t* pw = scr + S_PW + wave * PW_BYTES;
     __bf16* hp = reinterpret_cast<__bf16*>(pw + PW_HP);
     __bf16* hv = reinterpret_cast<__bf16*>(pw + PW_HV);
-    float* lg = reinterpret_cast<float*>(pw + PW_LG);
     const float* sb1 = reinterpret_cast<const float*>(scr + S_B1);
     const float* sw2 = reinterpret_cast<const float*>(scr + S_W2);
     const float* sbp = reinterpret_cast<const float*>(scr + S_BP);
     const int* mylist = tlist + wave * MAXIT * 2;
+    int* hgl = reinterpret_cast<int*>(scr + S_HG);                 // leaf of each of the 32 head columns
+    float* lg = reinterpret_cast<float*>(scr + S_PW);              // [32 boards][64] logits, over the planes
+    float* vpart = reinterpret_cast<float*>(scr + S_PW + 32 * 64 * 4);   // [8 waves][32 boards] value partial sums
     uint8_t* dump = scr + S_DUMP + wave * 64;  // where results for the rows' zero cells go (never read back)
+    int nrounds = 0;
+    for (int w = 0; w < 8; ++w) {
+        int nt = 0;
+        while (nt < MAXIT && tlist[(w * MAXIT + nt) * 2] >= 0) ++nt;
+        nrounds = max(nrounds, (nt + 1) >> 1);
+    }
 
-    int hg0 = -1, hg1 = -1, hg2 = -1, hg3 = -1;   // leaves whose head planes wait in hp / hv (boards 0..3)
-    for (int iter = 0; iter < MAXIT; ++iter) {
-        const int games[2] = {mylist[2 * iter], mylist[2 * iter + 1]};
-        if (games[0] < 0) break;
-        const bool two = games[1] >= 0;
-        const int ntiles = two ? TILES_PER_WAVE : 2;
-        const uint8_t* sblob = blob;
-        asm volatile("" : "+s"(sblob));
-        stem(sblob, leaf_bb, games, bufY, sbias, wave, lane, ntiles);
-        for (int blk = 0; blk < num_blocks; ++blk) {
-            conv3x3<false>(w1, bufY, bufX, dump, sbias + 32, wave, lane, two);
-            conv3x3<true>(w2, bufX, bufY, dump, sbias + 64, wave, lane, two);
-        }
-
-        // Head weights are fetched here, per task: hoisted above the loop they would be spilled to
-        // scratch (the tower owns the register file).  The empty asm makes the pointer opaque so the
-        // loads stay below this point.
-        const uint8_t* hblob = blob;
-        asm volatile("" : "+s"(hblob));
-        // ---- 1x1 head convs as one 2-step MFMA: rows 0,1 = policy planes, row 2 = value plane.
-        // Tasks alternate between the two halves of the wave's head scratch (boards 0,1 / 2,3).
-        const int half = iter & 1;
-        if (half) { hg2 = games[0]; hg3 = games[1]; } else { hg0 = games[0]; hg1 = games[1]; }
-        {
+    for (int round = 0; round < nrounds; ++round) {
+        int hg0 = -1, hg1 = -1, hg2 = -1, hg3 = -1;
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            const int iter = 2 * round + half;
+            const int games[2] = {mylist[2 * iter], mylist[2 * iter + 1]};
+            if (games[0] < 0) break;
+            if (half) { hg2 = games[0]; hg3 = games[1]; } else { hg0 = games[0]; hg1 = games[1]; }
+            const bool two = games[1] >= 0;
+            const int ntiles = two ? TILES_PER_WAVE : 2;
+            const uint8_t* sblob = blob;
+            asm volatile("" : "+s"(sblob));
+            stem(sblob, leaf_bb, games, bufY, sbias, wave, lane, ntiles);
+            for (int blk = 0; blk < num_blocks; ++blk) {
+                conv3x3<false>(w1, bufY, bufX, dump, sbias + 32, wave, lane, two);
+                conv3x3<true>(w2, bufX, bufY, dump, sbias + 64, wave, lane, two);
+            }
+            // 1x1 head convs as one 2-step MFMA: rows 0,1 = policy planes, row 2 = value plane.  (Head
+            // weights are fetched where they are used: hoisted above the loop they would be spilled,
+            // the tower owns the register file; the empty asm keeps the loads below this point.)
+            const uint8_t* hblob = blob;
+            asm volatile("" : "+s"(hblob));
             const bf16x8 a0 = frag_ptr(hblob, OFF_HF, lane)[0], a1 = frag_ptr(hblob, OFF_HF, lane)[64];
 #pragma unroll 1
             for (int t = 0; t < ntiles; ++t) {
@@ -382,90 +392,90 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
                 }
             }
         }
-        // The fully connected heads run once per two tasks (four boards): their weights come from L2
-        // every time, and an MFMA has 32 columns to fill.
-        const bool last = iter + 1 == MAXIT || mylist[2 * iter + 2] < 0;
-        if (half == 0 && !last) continue;
-        const int bcol = lane & 3;             // MFMA columns 4..31 duplicate the four boards and are ignored
-        // ---- value head: FC 42->256 (+ReLU) as 8 row tiles, then 256->1 and tanh
+        if (lane < 4) hgl[wave * 4 + lane] = lane == 0 ? hg0 : lane == 1 ? hg1 : lane == 2 ? hg2 : hg3;
+        __syncthreads();                                   // every wave's planes are in place
+
+        const uint8_t* fblob = blob;
+        asm volatile("" : "+s"(fblob));
+        // head column c = board (c & 3) of wave (c >> 2)
+        const int c = lane & 31;
+        const uint8_t* cpl = scr + S_PW + (c >> 2) * PW_BYTES;
+        const __bf16* chp = reinterpret_cast<const __bf16*>(cpl + PW_HP) + (c & 3) * 96;
+        const __bf16* chv = reinterpret_cast<const __bf16*>(cpl + PW_HV) + (c & 3) * 48;
+        // ---- value head: FC 42->256 (+ReLU), this wave's 32 hidden units, then their share of 256->1
+        float part = 0.0f;
         {
-            float part = 0.0f;
-#pragma unroll 2
-            for (int t = 0; t < 8; ++t) {
-                f32x16 acc;
+            f32x16 acc;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+            for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
 #pragma unroll
-                for (int s = 0; s < 3; ++s) {
-                    const bf16x8 a = frag_ptr(hblob, OFF_F1 + (t * 3 + s) * 1024, lane)[0];
-                    const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(hv + bcol * 48 + 16 * s + 8 * h);
-                    acc = MFMA(a, bfr, acc);
-                }
+            for (int s = 0; s < 3; ++s) {
+                const bf16x8 a = frag_ptr(fblob, OFF_F1 + (wave * 3 + s) * 1024, lane)[0];
+                acc = MFMA(a, *reinterpret_cast<const bf16x8*>(chv + 16 * s + 8 * h), acc);
+            }
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(sb1 + 32 * t + 8 * g + 4 * h);
-                    const f32x4 wv = *reinterpret_cast<const f32x4*>(sw2 + 32 * t + 8 * g + 4 * h);
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(sb1 + 32 * wave + 8 * g + 4 * h);
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(sw2 + 32 * wave + 8 * g + 4 * h);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) part = fmaf(fmaxf(acc[4 * g + i] + b1[i], 0.0f), wv[i], part);
-                }
+                for (int i = 0; i < 4; ++i) part = fmaf(fmaxf(acc[4 * g + i] + b1[i], 0.0f), wv[i], part);
             }
             part += __shfl_xor(part, 32);
-            const int vg = lane == 0 ? hg0 : lane == 1 ? hg1 : lane == 2 ? hg2 : lane == 3 ? hg3 : -1;
-            if (vg >= 0) v_out[vg] = tanhf(part + reinterpret_cast<const float*>(hblob + OFF_B2)[0]);
         }
-        // ---- policy head: FC 84->42 as 2 row tiles (cells 0..31, 32..41).  The logits overwrite the
-        // head planes, so both tiles are accumulated before the first store.
-        {
-            f32x16 pacc[2];
+        // ---- policy head: FC 84->42, row tile `wave` (cells 0..31 / 32..41) on waves 0 and 1
+        f32x16 pacc;
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+        for (int i = 0; i < 16; ++i) pacc[i] = 0.0f;
+        if (wave < 2) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) pacc[t][i] = 0.0f;
-#pragma unroll
-                for (int s = 0; s < 6; ++s) {
-                    const bf16x8 a = frag_ptr(hblob, OFF_PF + (t * 6 + s) * 1024, lane)[0];
-                    const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(hp + bcol * 96 + 16 * s + 8 * h);
-                    pacc[t] = MFMA(a, bfr, pacc[t]);
-                }
-            }
-            if ((lane & 31) < 4) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 bp = *reinterpret_cast<const f32x4*>(sbp + 32 * t + 8 * g + 4 * h);
-                        f32x4 o4;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) o4[i] = pacc[t][4 * g + i] + bp[i];
-                        *reinterpret_cast<f32x4*>(lg + bcol * 64 + 32 * t + 8 * g + 4 * h) = o4;
-                    }
+            for (int s = 0; s < 6; ++s) {
+                const bf16x8 a = frag_ptr(fblob, OFF_PF + (wave * 6 + s) * 1024, lane)[0];
+                pacc = MFMA(a, *reinterpret_cast<const bf16x8*>(chp + 16 * s + 8 * h), pacc);
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // lg written by lanes 0..3 and 32..35, read below
-        float pr = 0.0f;
-        int gidx = -1, c = 0;
-        if (lane < 32) {
+        __syncthreads();                                   // all planes consumed: logits may overwrite them
+        if (lane < 32) vpart[wave * 32 + c] = part;
+        if (wave < 2) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bp = *reinterpret_cast<const f32x4*>(sbp + 32 * wave + 8 * g + 4 * h);
+                f32x4 o4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o4[i] = pacc[4 * g + i] + bp[i];
+                *reinterpret_cast<f32x4*>(lg + c * 64 + 32 * wave + 8 * g + 4 * h) = o4;
+            }
+        }
+        __syncthreads();
+        if (tid < 256) {
             // landing-cell gather (connectfour.py:56-71) + soft-max over legal columns (mcts.py:106)
-            const int b = lane >> 3;
-            c = lane & 7;
-            gidx = b == 0 ? hg0 : b == 1 ? hg1 : b == 2 ? hg2 : hg3;
+            const int b = tid >> 3, col = tid & 7;
+            const int gidx = hgl[b];
             uint64_t occ = 0;
             if (gidx >= 0) occ = leaf_bb[2 * (size_t)gidx] | leaf_bb[2 * (size_t)gidx + 1];
-            const int height = c < 7 ? __popcll((occ >> (7 * c)) & 0x3Full) : 6;
-            const bool legal = c < 7 && height < 6;
-            const float logit = legal ? lg[b * 64 + height * 7 + c] : -INFINITY;
+            const int height = col < 7 ? __popcll((occ >> (7 * col)) & 0x3Full) : 6;
+            const bool legal = col < 7 && height < 6;
+            const float logit = legal ? lg[b * 64 + height * 7 + col] : -INFINITY;
             float m = logit;
             m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4));
             const float e = legal ? __expf(logit - m) : 0.0f;
             float sum = e;
             sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
-            pr = legal ? e / sum : 0.0f;
+            if (col < 7 && gidx >= 0) p_out[(size_t)gidx * 7 + col] = legal ? e / sum : 0.0f;
+        } else if (tid < 256 + 32) {
+            const int b = tid - 256;
+            const int gidx = hgl[b];
+            float sv = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) sv += vpart[w * 32 + b];
+            if (gidx >= 0) v_out[gidx] = tanhf(sv + reinterpret_cast<const float*>(fblob + OFF_B2)[0]);
         }
-        if (lane < 32 && c < 7 && gidx >= 0) p_out[(size_t)gidx * 7 + c] = pr;
-        // the planes' k-padding (cells 42..47 and 84..95) must read as zero again for the next pass
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        for (int i = lane; i < PW_BYTES / 4; i += 64) reinterpret_cast<uint32_t*>(pw)[i] = 0u;
-        hg0 = hg1 = hg2 = hg3 = -1;
+        if (round + 1 < nrounds) {
+            // the planes (and their k-padding) must read as zero again before the next round fills them
+            __syncthreads();
+            for (int i = tid; i < 8 * PW_BYTES / 16; i += NTHREADS)
+                reinterpret_cast<uint4*>(scr + S_PW)[i] = make_uint4(0, 0, 0, 0);
+            __syncthreads();
+        }
     }
 }
 
