@@ -181,36 +181,48 @@ __device__ __forceinline__ void stem(const uint8_t* blob, const uint64_t* leaf_b
                                      const float* bias, int wave, int lane, int ntiles) {
     const int h = lane >> 5;
     const bf16x8 a0 = frag_ptr(blob, OFF_SF, lane)[0], a1 = frag_ptr(blob, OFF_SF, lane)[64];
+    // both boards' bitboards are requested before the first tile needs them: one memory latency per task
+    uint64_t bbs[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        if (games[i] >= 0) {
+            bbs[2 * i] = leaf_bb[2 * (size_t)games[i]] << 8;
+            bbs[2 * i + 1] = leaf_bb[2 * (size_t)games[i] + 1] << 8;
+        }
 #pragma unroll 1
     for (int t = 0; t < ntiles; ++t) {
         const int R = (wave * TILES_PER_WAVE + t) * 32 + (lane & 31);
         const int b = R / 48, o = R - b * 48;
         const int pos = b * BOARD_POS + POS0 + o;
         const int y = o >> 3, x = o & 7;
-        const int gidx = games[b - 2 * wave];
-        uint64_t bb[2] = {0, 0};
-        if (gidx >= 0) { bb[0] = leaf_bb[2 * (size_t)gidx] << 8; bb[1] = leaf_bb[2 * (size_t)gidx + 1] << 8; }
+        const bool second = b != 2 * wave;
+        const uint64_t bb[2] = {second ? bbs[2] : bbs[0], second ? bbs[3] : bbs[1]};
         // after the shift, cell (xx, yy) with xx in -1..7, yy in -1..6 is bit (xx+1)*7 + yy + 1;
-        // out-of-board neighbours fall on guard bits, which are zero
-        bf16x8 f[2];
+        // out-of-board neighbours fall on guard bits, which are zero.  Three rows of one window
+        // column are three consecutive bits, so six 64-bit shifts fetch the whole 3x3x2 window;
+        // m18 collects it as bit k = 2 * tap + plane, tap = 3 * row + column of the window.
+        uint32_t m18 = 0;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int plane = 0; plane < 2; ++plane)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                // k = 16*s + 8*h + j; both values of h are formed and one selected, so that tap
-                // offsets stay compile-time constants
-                float v = 0.0f;
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const int k = 16 * s + 8 * hh + j, tap = k >> 1, plane = k & 1;
-                    if (tap < 9) {
-                        const int sh = (x + tap % 3) * 7 + (y + tap / 3);     // (x+tx-1+1)*7 + (y+ty-1) + 1
-                        const float bit = (float)((bb[plane] >> sh) & 1ull);
-                        v = (hh == h) ? bit : v;
-                    }
-                }
-                f[s][j] = (__bf16)v;
+            for (int tx = 0; tx < 3; ++tx) {
+                const uint32_t c3 = (uint32_t)(bb[plane] >> ((x + tx) * 7 + y)) & 7u;       // rows ty = 0, 1, 2
+                m18 |= ((c3 * 0x421u) & 0x1041u) << (2 * tx + plane);                      // to bits 0, 6, 12
             }
+        // fragment s holds k = 16 s + 8 h + j, j = 0..7, as bf16 1.0 / 0.0: two per dword
+        const uint32_t k8 = (m18 >> (8 * h)) & 0xFFu, k2 = h ? 0u : (m18 >> 16) & 3u;
+        uint32_t d[5];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t t2 = (k8 >> (2 * i)) & 3u;
+            d[i] = (t2 & 1u) * 0x3F80u + (t2 >> 1) * 0x3F800000u;
+        }
+        d[4] = (k2 & 1u) * 0x3F80u + (k2 >> 1) * 0x3F800000u;
+        bf16x8 f[2];
+        {
+            const uint4 f0 = make_uint4(d[0], d[1], d[2], d[3]), f1 = make_uint4(d[4], 0u, 0u, 0u);
+            f[0] = __builtin_bit_cast(bf16x8, f0);
+            f[1] = __builtin_bit_cast(bf16x8, f1);
         }
         f32x16 acc = bias_acc(bias, h);
         acc = MFMA(a0, f[0], acc);
