@@ -76,6 +76,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
 struct Weights { bf16x8 f[18]; };
 
 __device__ __forceinline__ const bf16x8* frag_ptr(const uint8_t* blob, int off, int lane) {
@@ -409,8 +411,12 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
 
         const uint8_t* fblob = blob;
         asm volatile("" : "+s"(fblob));
-        // head column c = board (c & 3) of wave (c >> 2)
-        const int c = lane & 31;
+        // Thread indices are re-derived from an opaque copy: every address of this phase is then
+        // computed here, per round, instead of being kept (and spilled) across the tower.
+        int ht = tid;
+        asm volatile("" : "+v"(ht));
+        const int hl = ht & 63, hh = hl >> 5, hw = uni(ht >> 6);
+        const int c = hl & 31;                                 // head column c = board (c & 3) of wave (c >> 2)
         const uint8_t* cpl = scr + S_PW + (c >> 2) * PW_BYTES;
         const __bf16* chp = reinterpret_cast<const __bf16*>(cpl + PW_HP) + (c & 3) * 96;
         const __bf16* chv = reinterpret_cast<const __bf16*>(cpl + PW_HV) + (c & 3) * 48;
@@ -422,13 +428,13 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
             for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
 #pragma unroll
             for (int s = 0; s < 3; ++s) {
-                const bf16x8 a = frag_ptr(fblob, OFF_F1 + (wave * 3 + s) * 1024, lane)[0];
-                acc = MFMA(a, *reinterpret_cast<const bf16x8*>(chv + 16 * s + 8 * h), acc);
+                const bf16x8 a = frag_ptr(fblob, OFF_F1 + (hw * 3 + s) * 1024, hl)[0];
+                acc = MFMA(a, *reinterpret_cast<const bf16x8*>(chv + 16 * s + 8 * hh), acc);
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 b1 = *reinterpret_cast<const f32x4*>(sb1 + 32 * wave + 8 * g + 4 * h);
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(sw2 + 32 * wave + 8 * g + 4 * h);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(sb1 + 32 * hw + 8 * g + 4 * hh);
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(sw2 + 32 * hw + 8 * g + 4 * hh);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) part = fmaf(fmaxf(acc[4 * g + i] + b1[i], 0.0f), wv[i], part);
             }
@@ -438,29 +444,29 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
         f32x16 pacc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) pacc[i] = 0.0f;
-        if (wave < 2) {
+        if (hw < 2) {
 #pragma unroll
             for (int s = 0; s < 6; ++s) {
-                const bf16x8 a = frag_ptr(fblob, OFF_PF + (wave * 6 + s) * 1024, lane)[0];
-                pacc = MFMA(a, *reinterpret_cast<const bf16x8*>(chp + 16 * s + 8 * h), pacc);
+                const bf16x8 a = frag_ptr(fblob, OFF_PF + (hw * 6 + s) * 1024, hl)[0];
+                pacc = MFMA(a, *reinterpret_cast<const bf16x8*>(chp + 16 * s + 8 * hh), pacc);
             }
         }
         __syncthreads();                                   // all planes consumed: logits may overwrite them
-        if (lane < 32) vpart[wave * 32 + c] = part;
-        if (wave < 2) {
+        if (hl < 32) vpart[hw * 32 + c] = part;
+        if (hw < 2) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 bp = *reinterpret_cast<const f32x4*>(sbp + 32 * wave + 8 * g + 4 * h);
+                const f32x4 bp = *reinterpret_cast<const f32x4*>(sbp + 32 * hw + 8 * g + 4 * hh);
                 f32x4 o4;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) o4[i] = pacc[4 * g + i] + bp[i];
-                *reinterpret_cast<f32x4*>(lg + c * 64 + 32 * wave + 8 * g + 4 * h) = o4;
+                *reinterpret_cast<f32x4*>(lg + c * 64 + 32 * hw + 8 * g + 4 * hh) = o4;
             }
         }
         __syncthreads();
-        if (tid < 256) {
+        if (ht < 256) {
             // landing-cell gather (connectfour.py:56-71) + soft-max over legal columns (mcts.py:106)
-            const int b = tid >> 3, col = tid & 7;
+            const int b = ht >> 3, col = ht & 7;
             const int gidx = hgl[b];
             uint64_t occ = 0;
             if (gidx >= 0) occ = leaf_bb[2 * (size_t)gidx] | leaf_bb[2 * (size_t)gidx + 1];
@@ -473,8 +479,8 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
             float sum = e;
             sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
             if (col < 7 && gidx >= 0) p_out[(size_t)gidx * 7 + col] = legal ? e / sum : 0.0f;
-        } else if (tid < 256 + 32) {
-            const int b = tid - 256;
+        } else if (ht < 256 + 32) {
+            const int b = ht - 256;
             const int gidx = hgl[b];
             float sv = 0.0f;
 #pragma unroll
