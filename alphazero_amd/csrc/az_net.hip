@@ -264,24 +264,26 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
     if (tid < 64) reinterpret_cast<float*>(scr + S_BP)[tid] = reinterpret_cast<const float*>(blob + OFF_BP)[tid];
 
     // ---- which leaves does each wave evaluate?  Only leaves that need the network (kind EVAL or
-    // ROOT in leaf_info) count.  The E of them are dealt out in rank order, as evenly as possible:
-    // wave slot s takes base + (s < rem) consecutive ranks (base = E / slots, rem = E % slots) and
-    // walks through them two at a time.  Slot s = workgroup s % gridDim, wave s / gridDim: the slots
-    // with one leaf more are waves 0..3 first, which sit on four different SIMDs.  Every workgroup
+    // ROOT in leaf_info) count.  The E of them are dealt out in rank order to SIMDs first: waves w and
+    // w + 4 of a workgroup share a SIMD, and that pair (unit u = workgroup + gridDim * w, w < 4) takes
+    // L = base + (u < rem) consecutive ranks (base = E / units, rem = E % units).  Inside the pair
+    // wave w + 4 takes an even number b = 2 * ((L + 1) / 4) of them and wave w the rest, so at most one
+    // of the pair's tasks is a single board (2 tiles for one leaf instead of 3 for two).  Every workgroup
     // scans the (L2-resident) leaf_info array itself: no extra launch, no atomics, deterministic.
     int* tlist = reinterpret_cast<int*>(scr + S_TL);
     int* wtot = reinterpret_cast<int*>(scr + S_WT);
     if (tid < 8 * MAXIT * 2) tlist[tid] = -1;
     __syncthreads();
-    const int NW = (int)gridDim.x * 8;
+    const int NU = (int)gridDim.x * 4;
     if (!leaf_info) {
         // dense mode: every leaf is evaluated, rank = leaf index
         if (tid < 8 * MAXIT * 2) {
             const int w = tid / (MAXIT * 2), pos = tid % (MAXIT * 2);
-            const int slot = (int)blockIdx.x + (int)gridDim.x * w;
-            const int base = n / NW, rem = n - base * NW;
-            const int start = slot * base + min(slot, rem), len = base + (slot < rem);
-            if (pos < len) tlist[tid] = start + pos;
+            const int unit = (int)blockIdx.x + (int)gridDim.x * (w & 3);
+            const int base = n / NU, rem = n - base * NU;
+            const int start = unit * base + min(unit, rem), len = base + (unit < rem);
+            const int nb = 2 * ((len + 1) >> 2), na = len - nb;
+            if (w < 4 ? pos < na : pos < nb) tlist[tid] = start + (w < 4 ? 0 : na) + pos;
         }
     } else {
         // thread t owns games [t*per, t*per + per); `per` is rounded up to a multiple of 4 so the
@@ -319,22 +321,25 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
             before += (w < wave) ? t : 0;
             total += t;
         }
-        // ranks [rank, rank + cnt) belong to this thread: find the slot of the first one with one
-        // division, then step through slots as the ranks run out of them
+        // ranks [rank, rank + cnt) belong to this thread: find the unit of the first one with one
+        // division, then step through units as the ranks run out of them
         if (cnt) {
             const int rank = before + incl - cnt;
-            const int base = total / NW, rem = total - base * NW;
-            const int big = rem * (base + 1);           // ranks below this sit in slots of base + 1
-            int slot, pos;
-            if (rank < big) { slot = rank / (base + 1); pos = rank - slot * (base + 1); }
-            else { const int q = (rank - big) / base; slot = rem + q; pos = rank - big - q * base; }
-            int len = base + (slot < rem);
+            const int base = total / NU, rem = total - base * NU;
+            const int big = rem * (base + 1);           // ranks below this sit in units of base + 1
+            int unit, pos;
+            if (rank < big) { unit = rank / (base + 1); pos = rank - unit * (base + 1); }
+            else { const int q = (rank - big) / base; unit = rem + q; pos = rank - big - q * base; }
+            int len = base + (unit < rem);
             while (mask) {
                 const int j = __ffsll((long long)mask) - 1;
                 mask &= mask - 1;
-                if ((slot & ((int)gridDim.x - 1)) == (int)blockIdx.x && pos < MAXIT * 2)
-                    tlist[(slot >> grid_shift) * MAXIT * 2 + pos] = g0 + j;
-                if (++pos == len) { ++slot; pos = 0; len = base + (slot < rem); }
+                if ((unit & ((int)gridDim.x - 1)) == (int)blockIdx.x) {
+                    const int na = len - 2 * ((len + 1) >> 2);
+                    const int w = (unit >> grid_shift) + (pos < na ? 0 : 4), q = pos < na ? pos : pos - na;
+                    if (q < MAXIT * 2) tlist[w * MAXIT * 2 + q] = g0 + j;
+                }
+                if (++pos == len) { ++unit; pos = 0; len = base + (unit < rem); }
             }
         }
     }
