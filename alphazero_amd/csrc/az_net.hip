@@ -154,7 +154,12 @@ __device__ __forceinline__ void conv3x3(const Weights& w, const uint8_t* src, ui
         keep[t] = (o & 7) != 7;
         base[t] = src + posb[t] + (h * 16 - 9 * PSTRIDE);
     }
+    // The epilogue of tile t-1 (vector ALU and LDS stores) is placed after the first MFMAs of tile t,
+    // which need nothing from it, so it runs while the matrix pipe works; only the last tile's
+    // epilogue stands alone.  (dst is never the source of this conv, so the early MFMAs of tile t do
+    // not read what tile t-1 still has to store.)
     bf16x8 fa[6], fb[6];
+    f32x16 prev;
     load_taps(fa, base[0], 0);
 #pragma unroll
     for (int t = 0; t < TILES_PER_WAVE; ++t) {
@@ -163,19 +168,22 @@ __device__ __forceinline__ void conv3x3(const Weights& w, const uint8_t* src, ui
         load_taps(fb, base[t], 1);
 #pragma unroll
         for (int i = 0; i < 6; ++i) acc = MFMA(w.f[i], fa[i], acc);
+        // the zero cell that closes each row is computed like a cell; its result goes to a dump row
+        if (t > 0) store_tile<RES>(prev, (keep[t - 1] ? dst + posb[t - 1] : dump) + h * 8);
         load_taps(fa, base[t], 2);
 #pragma unroll
         for (int i = 0; i < 6; ++i) acc = MFMA(w.f[6 + i], fb[i], acc);
         if (t + 1 < TILES_PER_WAVE) load_taps(fb, base[t + 1], 0);
 #pragma unroll
         for (int i = 0; i < 6; ++i) acc = MFMA(w.f[12 + i], fa[i], acc);
-        // the zero cell that closes each row is computed like a cell; its result goes to a dump row
-        store_tile<RES>(acc, (keep[t] ? dst + posb[t] : dump) + h * 8);
+        prev = acc;
         if (t + 1 < TILES_PER_WAVE) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) fa[i] = fb[i];
         }
     }
+    const int tl = two ? 2 : 1;
+    store_tile<RES>(prev, (keep[tl] ? dst + posb[tl] : dump) + h * 8);
 }
 
 // stem conv 2 -> C straight from bitboards: B[k][pos], k = tap*2 + plane (18 of 32 used)
