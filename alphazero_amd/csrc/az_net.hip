@@ -3,10 +3,10 @@
 // The whole network of alphazero/models.py:70-87 + alphazero/games/connectfour.py:54-72
 // (stem conv, tower of one residual block applied num_blocks times, policy and value
 // heads, landing-cell gather, soft-max over legal columns) runs in ONE kernel for up to
-// 32 trunk channels.  A persistent workgroup takes 16 leaf positions at a time straight
-// from their bitboards, keeps every activation in LDS from the first conv to the last and
-// writes only p[7] and v per leaf: HBM traffic is 16 B in and 32 B out per leaf, so the
-// kernel is bounded by the matrix-core rate, not by memory.
+// 32 trunk channels.  A workgroup (one per CU, 8 waves) takes its leaf positions straight
+// from their bitboards, two boards per wave at a time, keeps every activation in LDS from
+// the first conv to the last and writes only p[7] and v per leaf: HBM traffic is 16 B in
+// and 32 B out per leaf, so the kernel is bounded by the matrix-core rate, not by memory.
 //
 // Every contraction is an MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulate), oriented
 // D[out][pos] = sum_k Wt[out][k] X[k][pos]:
@@ -24,7 +24,7 @@
 // ds_read_b128 group always land on 16 different slots).  Board b owns 56 positions: one
 // zero row, then 6 rows of 7 cells + 1 zero cell; the zero row of board b+1 closes board b.
 // A 3x3 tap is therefore a constant byte offset folded into the ds_read instruction; the
-// 8th column is computed like a cell and masked back to zero when stored.
+// 8th column is computed like a cell and its result is stored to a dump row instead.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -35,7 +35,7 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-#define TB 16                     // boards per workgroup iteration
+#define TB 16                     // boards in the LDS images: two per wave
 #define PSTRIDE 80                // bytes per position
 #define BOARD_POS 56              // positions per board (zero row + 6 rows of 8)
 #define POS0 9                    // guard + zero row
