@@ -87,6 +87,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise AzError(f'{LIB_PATH} not found: build it with `make -C alphazero_amd/csrc` '
                       '(python -c "import __graft_entry__ as g; g.build()")')
+    # The library is meant to sit next to PyTorch-ROCm in one process and to share its HIP runtime
+    # (streams and device pointers cross the boundary): torch is loaded first, so that the
+    # libamdhip64 it ships is the one both bind to.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
