@@ -252,11 +252,39 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
     float* sbias = reinterpret_cast<float*>(scr + S_BIAS);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5;
 
-    // zero everything once: padding cells and the k-padding of the head planes are never written again
+    // zero everything once: padding cells and the k-padding of the head planes are never written
+    // again, and an empty entry of the task list is 0 (entries hold leaf index + 1)
     {
         uint4* z = reinterpret_cast<uint4*>(lds);
         for (int i = tid; i < LDS_BYTES / 16; i += NTHREADS) z[i] = make_uint4(0, 0, 0, 0);
     }
+    // Memory requests go out in the order in which their data is needed: the small head / bias tables,
+    // then this thread's slice of leaf_info, and only then the 36 KB of tower weights per wave (loads
+    // return in order, so whatever is waited for first must not queue behind the weights).
+    float t_bias = 0.0f, t_b1 = 0.0f, t_w2 = 0.0f, t_bp = 0.0f;
+    if (tid < 100) t_bias = reinterpret_cast<const float*>(blob + OFF_BIAS)[tid];
+    if (tid < 256) {
+        t_b1 = reinterpret_cast<const float*>(blob + OFF_B1)[tid];
+        t_w2 = reinterpret_cast<const float*>(blob + OFF_W2)[tid];
+    }
+    if (tid < 64) t_bp = reinterpret_cast<const float*>(blob + OFF_BP)[tid];
+    // thread t scans games [t*per, t*per + per); `per` is rounded up to a multiple of 4 so the kinds
+    // arrive as 16-byte loads; the first 16 games of the slice are requested here
+    const int per = ((n + NTHREADS - 1) / NTHREADS + 3) & ~3;
+    const int g0 = tid * per;
+    auto load4 = [&](int g) {
+        int4 k4 = make_int4(0, 0, 0, 0);
+        if (g + 3 < n) k4 = *reinterpret_cast<const int4*>(leaf_info + g);
+        else {
+            if (g < n) k4.x = leaf_info[g];
+            if (g + 1 < n) k4.y = leaf_info[g + 1];
+            if (g + 2 < n) k4.z = leaf_info[g + 2];
+        }
+        return k4;
+    };
+    int4 kfirst[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) kfirst[q] = (leaf_info && 4 * q < per) ? load4(g0 + 4 * q) : make_int4(0, 0, 0, 0);
     Weights w1, w2;
 #pragma unroll
     for (int s = 0; s < 18; ++s) {
@@ -264,12 +292,12 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
         w2.f[s] = frag_ptr(blob, OFF_WF + 18 * 1024, lane)[s * 64];
     }
     __syncthreads();
-    if (tid < 100) sbias[tid] = reinterpret_cast<const float*>(blob + OFF_BIAS)[tid];
+    if (tid < 100) sbias[tid] = t_bias;
     if (tid < 256) {
-        reinterpret_cast<float*>(scr + S_B1)[tid] = reinterpret_cast<const float*>(blob + OFF_B1)[tid];
-        reinterpret_cast<float*>(scr + S_W2)[tid] = reinterpret_cast<const float*>(blob + OFF_W2)[tid];
+        reinterpret_cast<float*>(scr + S_B1)[tid] = t_b1;
+        reinterpret_cast<float*>(scr + S_W2)[tid] = t_w2;
     }
-    if (tid < 64) reinterpret_cast<float*>(scr + S_BP)[tid] = reinterpret_cast<const float*>(blob + OFF_BP)[tid];
+    if (tid < 64) reinterpret_cast<float*>(scr + S_BP)[tid] = t_bp;
 
     // ---- which leaves does each wave evaluate?  Only leaves that need the network (kind EVAL or
     // ROOT in leaf_info) count.  The E of them are dealt out in rank order to SIMDs first: waves w and
@@ -280,9 +308,8 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
     // scans the (L2-resident) leaf_info array itself: no extra launch, no atomics, deterministic.
     int* tlist = reinterpret_cast<int*>(scr + S_TL);
     int* wtot = reinterpret_cast<int*>(scr + S_WT);
-    if (tid < 8 * MAXIT * 2) tlist[tid] = -1;
-    __syncthreads();
     const int NU = (int)gridDim.x * 4;
+    int E = n;                                 // leaves to evaluate in this launch
     if (!leaf_info) {
         // dense mode: every leaf is evaluated, rank = leaf index
         if (tid < 8 * MAXIT * 2) {
@@ -291,28 +318,22 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
             const int base = n / NU, rem = n - base * NU;
             const int start = unit * base + min(unit, rem), len = base + (unit < rem);
             const int nb = 2 * ((len + 1) >> 2), na = len - nb;
-            if (w < 4 ? pos < na : pos < nb) tlist[tid] = start + (w < 4 ? 0 : na) + pos;
+            if (w < 4 ? pos < na : pos < nb) tlist[tid] = start + (w < 4 ? 0 : na) + pos + 1;
         }
     } else {
-        // thread t owns games [t*per, t*per + per); `per` is rounded up to a multiple of 4 so the
-        // kinds arrive as 16-byte loads, and the "needs eval" flags stay in a register mask
-        const int per = ((n + NTHREADS - 1) / NTHREADS + 3) & ~3;
-        const int g0 = tid * per;
-        unsigned long long mask = 0;           // up to 64 games per thread (n <= 32768)
-        for (int j = 0; j < per; j += 4) {
-            const int g = g0 + j;
-            int4 k4 = make_int4(0, 0, 0, 0);
-            if (g + 3 < n) k4 = *reinterpret_cast<const int4*>(leaf_info + g);
-            else {
-                if (g < n) k4.x = leaf_info[g];
-                if (g + 1 < n) k4.y = leaf_info[g + 1];
-                if (g + 2 < n) k4.z = leaf_info[g + 2];
-            }
+        // the "needs eval" flags of the slice stay in a register mask: up to 64 games per thread (n <= 32768)
+        auto flags4 = [&](const int4& k4) {
             const int ks[4] = {k4.x & 0xFF, k4.y & 0xFF, k4.z & 0xFF, k4.w & 0xFF};
+            unsigned long long m = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (ks[i] == AZ_LEAF_EVAL || ks[i] == AZ_LEAF_ROOT) mask |= 1ull << (j + i);
-        }
+                if (ks[i] == AZ_LEAF_EVAL || ks[i] == AZ_LEAF_ROOT) m |= 1ull << i;
+            return m;
+        };
+        unsigned long long mask = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mask |= flags4(kfirst[q]) << (4 * q);
+        for (int j = 16; j < per; j += 4) mask |= flags4(load4(g0 + j)) << j;
         const int cnt = __popcll(mask);
         int incl = cnt;
 #pragma unroll
@@ -329,6 +350,7 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
             before += (w < wave) ? t : 0;
             total += t;
         }
+        E = total;
         // ranks [rank, rank + cnt) belong to this thread: find the unit of the first one with one
         // division, then step through units as the ranks run out of them
         if (cnt) {
@@ -345,7 +367,7 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
                 if ((unit & ((int)gridDim.x - 1)) == (int)blockIdx.x) {
                     const int na = len - 2 * ((len + 1) >> 2);
                     const int w = (unit >> grid_shift) + (pos < na ? 0 : 4), q = pos < na ? pos : pos - na;
-                    if (q < MAXIT * 2) tlist[w * MAXIT * 2 + q] = g0 + j;
+                    if (q < MAXIT * 2) tlist[w * MAXIT * 2 + q] = g0 + j + 1;
                 }
                 if (++pos == len) { ++unit; pos = 0; len = base + (unit < rem); }
             }
@@ -370,11 +392,12 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
     float* lg = reinterpret_cast<float*>(scr + S_PW);              // [32 boards][64] logits, over the planes
     float* vpart = reinterpret_cast<float*>(scr + S_PW + 32 * 64 * 4);   // [8 waves][32 boards] value partial sums
     uint8_t* dump = scr + S_DUMP + wave * 64;  // where results for the rows' zero cells go (never read back)
-    int nrounds = 0;
-    for (int w = 0; w < 8; ++w) {
-        int nt = 0;
-        while (nt < MAXIT && tlist[(w * MAXIT + nt) * 2] >= 0) ++nt;
-        nrounds = max(nrounds, (nt + 1) >> 1);
+    // the longest list of this workgroup is wave 0's (unit = blockIdx is its lowest unit): 4 leaves per round
+    int nrounds;
+    {
+        const int base = E / NU, rem = E - base * NU;
+        const int len = base + ((int)blockIdx.x < rem), na = len - 2 * ((len + 1) >> 2);
+        nrounds = (min(na, MAXIT * 2) + 3) >> 2;
     }
 
     for (int round = 0; round < nrounds; ++round) {
@@ -382,7 +405,7 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
             const int iter = 2 * round + half;
-            const int games[2] = {mylist[2 * iter], mylist[2 * iter + 1]};
+            const int games[2] = {mylist[2 * iter] - 1, mylist[2 * iter + 1] - 1};
             if (games[0] < 0) break;
             if (half) { hg2 = games[0]; hg3 = games[1]; } else { hg0 = games[0]; hg1 = games[1]; }
             const bool two = games[1] >= 0;
