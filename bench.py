@@ -313,7 +313,7 @@ def main():
             out['roofline'] = {'kernel': 'k_run_uniform<GameC4>', 'bound': 'hbm', 'achieved': gbs,
                                'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
                                'traffic': None, 'avg_launch_ms': ms, 'bytes_per_sim': bps}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the host-CPU baseline is timed at N = 1 only
             workers = min(16, os.cpu_count() or 1)
             pps, sps, npos, wall = cpu_baseline(args.model, S, args.cpu_seconds, workers)
             out['cpu_baseline'] = {'value': pps, 'unit': 'positions/s', 'sims_per_s': sps, 'cores': workers,
