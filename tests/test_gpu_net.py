@@ -181,3 +181,40 @@ def test_trunk128_evaluates_only_leaves_that_need_it():
         act = (kind == 1) | (kind == 3)
         assert torch.equal(p[act], dense_p[act]) and torch.equal(v[act], dense_v[act])
         assert torch.all(p[~act] == -7.0) and torch.all(v[~act] == -7.0)
+
+
+@pytest.mark.parametrize('n', [1, 2, 3, 5, 255, 2047, 2049, 4097, 16385, 32768])
+def test_fused_forward_is_independent_of_batch_shape(n):
+    """A leaf's outputs do not depend on how the launch deals leaves to waves: the same positions
+    evaluated in one batch of n (dense), with a random subset marked (packed) and in two halves
+    give the same bits."""
+    from alphazero_amd import engine as E
+    from alphazero_amd.models import AlphaZeroC4
+    from alphazero_amd.net import FusedC4Net
+    torch.manual_seed(1)
+    model = AlphaZeroC4(1, 8).eval()
+    base = _random_positions(min(n, 400), 41)
+    hists = [base[(i * 13) % len(base)] for i in range(n)]
+    bb, nm = E.positions_from_history(1, hists)
+    legal, _, _ = E.game_query(1, bb, nm)
+    net = FusedC4Net.from_module(model, 'cuda')
+    p0, v0 = net(bb, None)
+    p0, v0 = p0.clone(), v0.clone()
+    assert torch.allclose(p0.sum(1), torch.ones(n, device='cuda'), atol=1e-5)
+    # identical positions give identical rows, wherever they sit in the batch
+    if n > len(base):
+        j = [i for i in range(1, n) if (i * 13) % len(base) == 0][0]
+        assert torch.equal(p0[0], p0[j]) and torch.equal(v0[0], v0[j])
+    rng = np.random.RandomState(n)
+    kind = torch.from_numpy(rng.choice([0, 1, 2, 3], size=n, p=[0.2, 0.6, 0.1, 0.1]).astype(np.int32)).cuda()
+    net._p.fill_(-7.0)
+    net._v.fill_(-7.0)
+    p1, v1 = net(bb, ((legal << 16) | kind).to(torch.int32))
+    act = (kind == 1) | (kind == 3)
+    assert torch.equal(p1[act], p0[act]) and torch.equal(v1[act], v0[act])
+    assert torch.all(p1[~act] == -7.0) and torch.all(v1[~act] == -7.0)
+    if n >= 2:
+        h = n // 2
+        net2 = FusedC4Net.from_module(model, 'cuda')
+        pa, va = net2(bb[:h].contiguous(), None)
+        assert torch.equal(pa, p0[:h]) and torch.equal(va, v0[:h])
