@@ -316,8 +316,13 @@ def main():
         if not args.no_cpu_baseline and world == 1:      # the host-CPU baseline is timed at N = 1 only
             workers = min(16, os.cpu_count() or 1)
             pps, sps, npos, wall = cpu_baseline(args.model, S, args.cpu_seconds, workers)
+            try:        # oracle speed / reference-Python speed, measured in the build container (tools/ref_ratio.py)
+                ratio = json.load(open(os.path.join(ROOT, 'profiles', 'r01_ref_vs_oracle_cpu.json')))['oracle_over_reference']
+            except (OSError, KeyError, ValueError):
+                ratio = None
             out['cpu_baseline'] = {'value': pps, 'unit': 'positions/s', 'sims_per_s': sps, 'cores': workers,
-                                   'kind': 'port',
+                                   'kind': 'port', 'oracle_over_reference_python': ratio,
+                                   'reference_python_equivalent': pps / ratio if ratio else None,
                                    'sample': f'{npos} self-play moves ({S} sims each) by the CPU oracle in {wall:.1f} s: '
                                              f'{workers} independent single-game workers, one core and one net call '
                                              f'per leaf each, model {args.model}'}
