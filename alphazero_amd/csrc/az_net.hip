@@ -39,8 +39,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define PSTRIDE 80                // bytes per position
 #define BOARD_POS 56              // positions per board (zero row + 6 rows of 8)
 #define POS0 9                    // guard + zero row
+#define BOARD_PAD 128             // bytes skipped before every board, see board_off
 #define NPOS_TOTAL (1 + TB * BOARD_POS + 8 + 1)
-#define ACT_BYTES (((NPOS_TOTAL * PSTRIDE) + 255) / 256 * 256)
+#define ACT_BYTES (((NPOS_TOTAL * PSTRIDE + TB * BOARD_PAD) + 255) / 256 * 256)
 #define NTHREADS 512
 #define TILES_PER_WAVE 3          // TB*48/32 = 24 tiles of 32 positions over 8 waves
 
@@ -75,6 +76,13 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define BLOB_BYTES (OFF_B2 + 16)
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+// Byte offset of cell-grid position o (0..47) of board b in an activation image.  A tile of 32
+// positions can straddle two boards; going from one board to the next skips 8 positions (the zero
+// row), i.e. 40 slots of 16 B = 8 mod 16, which would put the two halves of a ds_read_b128 lane
+// group on the same slots.  128 bytes (8 slots) of never-written padding per board make the step a
+// multiple of 16 slots again; the padding extends the zero row, so taps across it still read zeros.
+__device__ __forceinline__ int board_off(int b, int o) { return (b * BOARD_POS + POS0 + o) * PSTRIDE + b * BOARD_PAD; }
 
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
@@ -150,7 +158,7 @@ __device__ __forceinline__ void conv3x3(const Weights& w, const uint8_t* src, ui
     for (int t = 0; t < TILES_PER_WAVE; ++t) {
         const int R = (wave * TILES_PER_WAVE + t) * 32 + (lane & 31);
         const int b = R / 48, o = R - b * 48;
-        posb[t] = (b * BOARD_POS + POS0 + o) * PSTRIDE;
+        posb[t] = board_off(b, o);
         keep[t] = (o & 7) != 7;
         base[t] = src + posb[t] + (h * 16 - 9 * PSTRIDE);
     }
@@ -203,7 +211,6 @@ __device__ __forceinline__ void stem(const uint8_t* blob, const uint64_t* leaf_b
     for (int t = 0; t < ntiles; ++t) {
         const int R = (wave * TILES_PER_WAVE + t) * 32 + (lane & 31);
         const int b = R / 48, o = R - b * 48;
-        const int pos = b * BOARD_POS + POS0 + o;
         const int y = o >> 3, x = o & 7;
         const bool second = b != 2 * wave;
         const uint64_t bb[2] = {second ? bbs[2] : bbs[0], second ? bbs[3] : bbs[1]};
@@ -237,7 +244,7 @@ __device__ __forceinline__ void stem(const uint8_t* blob, const uint64_t* leaf_b
         f32x16 acc = bias_acc(bias, h);
         acc = MFMA(a0, f[0], acc);
         acc = MFMA(a1, f[1], acc);
-        if (x != 7) store_tile<false>(acc, dst + pos * PSTRIDE + h * 8);
+        if (x != 7) store_tile<false>(acc, dst + board_off(b, o) + h * 8);
     }
 }
 
@@ -427,7 +434,7 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
             for (int t = 0; t < ntiles; ++t) {
                 const int R = (wave * TILES_PER_WAVE + t) * 32 + (lane & 31);
                 const int b = R / 48, o = R - b * 48;
-                const uint8_t* base = bufY + (b * BOARD_POS + POS0 + o) * PSTRIDE + h * 16;
+                const uint8_t* base = bufY + board_off(b, o) + h * 16;
                 f32x16 acc;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
