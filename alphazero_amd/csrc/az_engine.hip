@@ -747,6 +747,44 @@ __global__ void k_render(const uint64_t* bb, int n, float* x, uint8_t* valid) {
         valid[(size_t)i * GM::A + r] = (GM::legal(bb[2 * (size_t)i], bb[2 * (size_t)i + 1]) >> r) & 1u;
 }
 
+// replay_buffer.py:113-147 for every state of a batch of finished games: thread = state
+template <class GM>
+__global__ void k_examples(const az_game_record* __restrict__ recs, int nrec, const int32_t* __restrict__ state_offset,
+                           int total, float* __restrict__ x, float* __restrict__ p, float* __restrict__ z,
+                           uint8_t* __restrict__ valid, int32_t* __restrict__ version) {
+    constexpr int CELLS = GM::H * GM::W;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= total) return;
+    int lo = 0, hi = nrec;                           // last record whose first state is <= s
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (state_offset[mid] <= s) lo = mid; else hi = mid;
+    }
+    const az_game_record& r = recs[lo];
+    const int m = s - state_offset[lo];
+    uint64_t nx = 0, pv = 0;
+    int nm = 0;
+    for (int k = 0; k < m; ++k) GM::play(nx, pv, nm, r.history[k]);     // Game(history[:move_index])
+    const uint32_t legal = GM::legal(nx, pv);
+    // p[valid_actions] = n / np.sum(n), n as stored: int16 (replay_buffer.py:30-35), quotient in fp64
+    const int ne = r.num_edges[m];
+    long sum = 0;
+    for (int i = 0; i < ne; ++i) sum += (int16_t)r.visits[m][i];
+    for (int a = 0; a < GM::A; ++a) {
+        p[(size_t)s * GM::A + a] = 0.0f;
+        valid[(size_t)s * GM::A + a] = (legal >> a) & 1u;
+    }
+    for (int i = 0; i < ne; ++i)
+        p[(size_t)s * GM::A + az_nth_set_bit(legal, i)] = (float)((double)(int16_t)r.visits[m][i] / (double)sum);
+    // outcome for the player to move (game.py:42-47)
+    z[s] = r.winner < 0 ? 0.0f : ((m & 1) == r.winner ? 1.0f : -1.0f);
+    if (version) version[s] = r.model_version;
+    for (int c = 0; c < CELLS; ++c) {
+        x[(size_t)s * 2 * CELLS + c] = GM::cell(nx, c / GM::W, c % GM::W) ? 1.0f : 0.0f;
+        x[(size_t)s * 2 * CELLS + CELLS + c] = GM::cell(pv, c / GM::W, c % GM::W) ? 1.0f : 0.0f;
+    }
+}
+
 template <int A>
 __global__ void k_masked_softmax(const float* logits, const int32_t* info, int n, float* p) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1099,6 +1137,17 @@ int az_render(int32_t game, const uint64_t* bb, int32_t n, float* x, uint8_t* va
         hipLaunchKernelGGL((k_render<GM>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, bb,
                            (int)n, x, valid);
     });
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int az_examples_from_records(int32_t game, const az_game_record* records, int32_t n, const int32_t* state_offset,
+                             int32_t total, float* x, float* p, float* z, uint8_t* valid, int32_t* version,
+                             void* stream) {
+    if (n < 0 || total < 0 || (total && (!records || !state_offset || !x || !p || !z || !valid))) return fail("bad argument");
+    if (total == 0) return 0;
+    DISPATCH_GAME(game, hipLaunchKernelGGL((k_examples<GM>), dim3((total + 127) / 128), dim3(128), 0, (hipStream_t)stream,
+                                           records, (int)n, state_offset, (int)total, x, p, z, valid, version));
     LAUNCH_CHECK();
     return 0;
 }

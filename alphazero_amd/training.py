@@ -1,7 +1,9 @@
 """TrainingWorker with the reference's constructor and process_batch() contract
 (alphazero/training.py:15-125): SGD + momentum + weight decay, MultiStepLR, masked
 cross-entropy + MSE, weights published after every step.  Host-side torch code; the summary
-writer and model server are duck-typed (`add_scalar`, `update(model, version)`)."""
+writer and model server are duck-typed (`add_scalar`, `update(model, version)`).  `dataset` is a
+ReplayBufferDataset (the reference's per-state sample dicts) or a DeviceReplayWindow (batches taken
+straight from tensors on the GPU)."""
 import torch
 from torch.optim import SGD
 from torch.optim.lr_scheduler import MultiStepLR
@@ -27,6 +29,11 @@ class TrainingWorker:
         return self._model
 
     def _batch(self):
+        if hasattr(self._dataset, 'sample'):
+            # DeviceReplayWindow: the window already lives on the GPU as tensors
+            b = self._dataset.sample(self._config.training['batch_size'])
+            return (b['x'].to(self._device), b['p'].to(self._device), b['z'].to(self._device),
+                    b['p_valid'].to(self._device))
         items = [self._dataset[i] for i in next(self._sampler)]
         stack = lambda k, dt: torch.as_tensor(__import__('numpy').stack([it[k] for it in items])).to(self._device, dt)
         return stack('x', torch.float32), stack('p', torch.float32), stack('z', torch.float32), stack('p_valid', torch.bool)

@@ -143,6 +143,17 @@ int  az_drain_finished(az_engine* e, az_game_record* out_host, int32_t max_recor
                        int32_t* num_out, void* stream);
 int  az_get_stats(az_engine* e, az_stats* out_host, void* stream);
 
+/* Training examples of finished games, built on the device: what ReplayBufferDataset.__getitem__
+ * (alphazero/replay_buffer.py:113-147) returns for every state of n records, in game-major order.
+ * records = DEVICE az_game_record[n]; state_offset = DEVICE int32[n+1], exclusive prefix sum of
+ * num_moves (total = state_offset[n]).  Outputs (DEVICE): x float32[total][2][H][W] = render() of
+ * the position before move m, p float32[total][A] = visits / sum with the visits cast to int16 as
+ * the reference stores them (replay_buffer.py:30-35), z float32[total] = outcome for the player to
+ * move (game.py:42-47), valid uint8[total][A], version int32[total] (may be NULL).            */
+int  az_examples_from_records(int32_t game, const az_game_record* records, int32_t n, const int32_t* state_offset,
+                              int32_t total, float* x, float* p, float* z, uint8_t* valid, int32_t* version,
+                              void* stream);
+
 /* ---- tree transfer for the single-game MCTreeNode / run_mcts mirror ------
  * node image (HOST): uint32[num_nodes][A+1][4]; edge i = {N, W bits, P bits,
  * child index or AZ_NO_NODE}; last row = {num_edges, sum N, 0, 0}.

@@ -100,3 +100,89 @@ def test_c4_net_128_channels_uses_the_tower_kernel():
         assert w.play_game() == 3
     _check_games(ds, orc.C4, 16, True)
     assert w.engine.stats()['errors'] == 0
+
+
+@pytest.mark.parametrize('game_name', ['c4', 'ttt'])
+def test_device_replay_window_matches_the_dataset_mirror(game_name):
+    """az_examples_from_records against ReplayBufferDataset.__getitem__ (the reference's sample layout,
+    alphazero/replay_buffer.py:113-147) on games the engine played: x, p, z, p_valid, model_version
+    bit for bit, plus the window's wrap-around."""
+    from alphazero_amd import engine as E
+    from alphazero_amd.config import AlphaZeroConfig
+    from alphazero_amd.games import ConnectFour, TicTacToe
+    from alphazero_amd.replay_buffer import DeviceReplayWindow, ReplayBufferDataset
+    from alphazero_amd.selfplay import record_to_game
+    cls, mod = (ConnectFour, 'connectfour') if game_name == 'c4' else (TicTacToe, 'tictactoe')
+    cfg = AlphaZeroConfig(conf={'game': {'module': f'alphazero.games.{mod}', 'name': cls.__name__}})
+    eng = E.SelfPlayEngine(cls.AZ_GAME_ID, 96, 40, exploration_depth=3, reuse_search_tree=True, seed=7, device=0)
+    eng.set_model_version(11)
+    raws = []
+    while sum(r.shape[0] for r in raws) < 120:
+        eng.begin_move_uniform()
+        eng.run_sims_uniform(40)
+        eng.choose_and_advance()
+        r = eng.drain_finished_bytes()
+        if r.shape[0]:
+            raws.append(r.copy())
+    ds = ReplayBufferDataset(cfg)
+    win = DeviceReplayWindow(cls, capacity=1 << 16, device='cuda')
+    small = DeviceReplayWindow(cls, capacity=100, device='cuda')
+    for raw in raws:
+        for rec in [E.GameRecord.from_buffer_copy(raw[i].tobytes()) for i in range(raw.shape[0])]:
+            ds.add_game(record_to_game(cls, rec), int(rec.model_version))
+        assert win.add_records(raw) == sum(int(x) for x in raw[:, 8:12].copy().view(np.int32).reshape(-1))
+        small.add_records(raw)
+    assert len(win) == len(ds) and win.num_games == ds.num_games()
+    draws = 0
+    for i in range(len(ds)):
+        want, got = ds[i], win.state(i)
+        assert np.array_equal(want['x'], got['x'].cpu().numpy()), i
+        assert np.array_equal(want['p'], got['p'].cpu().numpy()), i          # bit-exact: fp64 quotient -> fp32
+        assert want['z'][0] == float(got['z'][0]) and want['model_version'] == got['model_version'] == 11
+        assert np.array_equal(want['p_valid'], got['p_valid'].cpu().numpy())
+        draws += want['z'][0] == 0
+    assert len(small) == 100
+    for i in range(100):                                                      # the window keeps the newest states
+        want, got = ds[len(ds) - 100 + i], small.state(i)
+        assert np.array_equal(want['p'], got['p'].cpu().numpy()) and np.array_equal(want['x'], got['x'].cpu().numpy())
+    batch = win.sample(64)
+    assert batch['x'].shape == (64,) + win.shape and batch['p_valid'].dtype == torch.bool
+    assert torch.allclose(batch['p'].sum(1), torch.ones(64, device='cuda'), atol=1e-6)
+    assert small.sample(256)['z'].shape == (256, 1)                           # larger than the window: with replacement
+
+
+def test_training_step_from_the_device_window():
+    """alphazero/training.py:42-75 with the batch taken from the on-device window: selfplay -> records ->
+    examples -> one SGD step, weights published."""
+    from alphazero_amd import engine as E
+    from alphazero_amd.games import ConnectFour
+    from alphazero_amd.replay_buffer import DeviceReplayWindow
+    from alphazero_amd.training import TrainingWorker
+    cfg = _config({'module': 'alphazero.games.connectfour', 'name': 'ConnectFour'},
+                  {'module': 'alphazero.games.connectfour', 'name': 'AlphaZeroC4',
+                   'kwargs': {'num_blocks': 1, 'channels_per_block': 8}}, S=16)
+    cfg._conf['loss'] = {'module': 'alphazero.loss', 'name': 'AlphaZeroLoss'}
+    cfg._conf['training'] = {'lr': 0.05, 'momentum': 0.9, 'weight_decay': 1e-4, 'lr_schedule': [100],
+                             'lr_schedule_gamma': 0.1, 'batch_size': 64}
+    eng = E.SelfPlayEngine(ConnectFour.AZ_GAME_ID, 64, 16, exploration_depth=4, reuse_search_tree=True, seed=3, device=0)
+    win = DeviceReplayWindow(ConnectFour, capacity=4096, device='cuda')
+    while len(win) < 64:
+        eng.begin_move_uniform()
+        eng.run_sims_uniform(16)
+        eng.choose_and_advance()
+        win.add_records(eng.drain_finished_bytes())
+
+    class _Pub:
+        def __init__(self):
+            self.updates = []
+
+        def update(self, model, version):
+            self.updates.append(version)
+
+    pub = _Pub()
+    torch.manual_seed(0)
+    tw = TrainingWorker(cfg, pub, win, None, 'cuda')
+    before = [p.detach().clone() for p in tw.model.parameters()]
+    assert tw.process_batch() == 1 and tw.process_batch() == 2 and pub.updates == [1, 2]
+    assert any(not torch.equal(a, b) for a, b in zip(before, tw.model.parameters()))
+    assert all(torch.isfinite(p).all() for p in tw.model.parameters())
