@@ -60,6 +60,19 @@ def _worker(rank, world, port, out_dir):
             assert torch.equal(v, ref0.state_dict()[k]), k
     sd = model.state_dict()
     assert sd['_tower.0._c1.weight'].data_ptr() == sd['_tower.1._c1.weight'].data_ptr()
+    # --- the same through ModelServer.sync (update on the trainer rank, latest everywhere)
+    from alphazero_amd.model_server import ModelServer
+    srv = ModelServer()
+    torch.manual_seed(100 + rank)
+    mine = AlphaZeroC4(2, 8)
+    if rank == 0:
+        srv.update(mine, 9)
+    assert srv.sync(mine, src=0) == 9
+    fresh = AlphaZeroC4(2, 8)
+    assert srv.latest(fresh) == 9
+    torch.manual_seed(100)
+    want = AlphaZeroC4(2, 8)
+    assert all(torch.equal(v, want.state_dict()[k]) for k, v in fresh.state_dict().items())
     # --- record gather: uneven counts, including an empty rank
     recs = _fake_records(rank, 0 if rank == 1 else 3)
     got = D.gather_records(recs, dst=0)

@@ -145,3 +145,29 @@ def test_replay_window_sample_layout(tmp_path):
     assert row[0] == 3 and row[1] == '0,2,8,4,6,7,3'
     assert np.array_equal(np.frombuffer(row[2], np.int16), np.concatenate([n for _, n in stats]).astype(np.int16))
     assert con.execute('SELECT COUNT(*) FROM game_states').fetchone()[0] == 7
+
+
+def test_model_server_and_checkpoint_format(tmp_path):
+    # alphazero/model_server.py:19-48: update / latest / periodic checkpoint {model_version, model_state_dict}
+    from alphazero_amd.model_server import ModelServer, load_ckpt
+    from alphazero_amd.models import AlphaZeroC4
+    torch.manual_seed(0)
+    a, b = AlphaZeroC4(3, 8), AlphaZeroC4(3, 8)
+    srv = ModelServer(str(tmp_path), ckpt_period=2)
+    assert srv.latest(b) == 0
+    srv.update(a, 1)
+    assert not os.path.exists(tmp_path / 'ckpt' / '000001.pt')
+    with torch.no_grad():
+        a._cbr[0].weight.add_(1.0)
+    srv.update(a, 2)
+    assert srv.latest(b) == 2
+    for (k, va), (_, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(va, vb), k
+    path = tmp_path / 'ckpt' / '000002.pt'
+    ck = torch.load(path, weights_only=True)
+    assert ck['model_version'] == 2 and set(ck['model_state_dict']) == set(a.state_dict())
+    assert any(k.startswith('_tower.2.') for k in ck['model_state_dict'])        # aliased block keys, as the reference saves them
+    c = AlphaZeroC4(3, 8)
+    assert load_ckpt(path, c) == 2 and torch.equal(c._cbr[0].weight, a._cbr[0].weight)
+    srv.reset()
+    assert srv.latest(b) == 0
