@@ -94,6 +94,13 @@ class SelfPlayWorker:
         self.games_finished += len(recs)
         return len(recs)
 
+    def collect_finished_bytes(self):
+        """Finished games as raw az_game_record bytes (uint8 [n, record size]); `dataset` is not
+        touched.  For loops that feed a DeviceReplayWindow or ship records to another rank."""
+        raw = self.engine.drain_finished_bytes().copy()
+        self.games_finished += raw.shape[0]
+        return raw
+
     def refresh_model(self):
         """selfplay.py:16-22: pull the latest weights; version 0 means 'no model yet'."""
         self._version = int(self._model_server.latest(self._model))

@@ -1,0 +1,56 @@
+"""Self-play and training in one loop, the shape of the reference's `_synchronous_play_and_train`
+(alphazero/train.py:85-95), for one GPU or one process per GPU:
+
+    every rank : SelfPlayWorker plays lock-step moves for its shard of the games
+    records    : raw az_game_record bytes, gathered on the trainer rank (RCCL) -- replaces the SQLite file
+    trainer    : DeviceReplayWindow.add_records -> TrainingWorker.process_batch (one SGD step)
+    weights    : ModelServer.update on the trainer rank, ModelServer.sync (one broadcast) everywhere
+
+Nothing here is on the measured hot path; it is the caller on either side of it."""
+import torch
+import torch.distributed as dist
+
+from .model_server import ModelServer
+from .replay_buffer import DeviceReplayWindow
+from .selfplay import SelfPlayWorker
+from .training import TrainingWorker
+
+
+def synchronous_play_and_train(config, device, num_games=1024, num_steps=None, moves_per_step=1, logdir=None,
+                               summary_writer=None, seed=0, trainer_rank=0, window_states=64 * 1024, log=None):
+    """Runs until the model version reaches `num_steps` (default: config.training['num_steps']).
+    Returns (model_server, selfplay_worker, training_worker or None)."""
+    multi = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank() if multi else 0
+    world = dist.get_world_size() if multi else 1
+    num_steps = int(num_steps if num_steps is not None else config.training['num_steps'])
+    server = ModelServer(logdir if rank == trainer_rank else None)
+    server.reset()
+    worker = SelfPlayWorker(config, server, None, device, num_games=num_games, seed=seed, rank=rank, world_size=world)
+    trainer = window = None
+    if rank == trainer_rank:
+        window = DeviceReplayWindow(type(config.Game()), window_states, device)
+        trainer = TrainingWorker(config, server, window, summary_writer, device)
+    version = 0
+    while version < num_steps:
+        # alphazero/selfplay.py:16-22: newest weights first (version 0 = UniformModel)
+        if multi:
+            server.sync(worker._model, src=trainer_rank)
+        worker.refresh_model()
+        uniform = worker._version <= 0
+        for _ in range(moves_per_step):
+            worker.play_move(uniform)
+        raw = worker.collect_finished_bytes()
+        if multi:
+            from .distributed import gather_record_bytes
+            raw = gather_record_bytes(raw, dst=trainer_rank, device=device)
+        if rank == trainer_rank:
+            window.add_records(raw)
+            version = trainer.process_batch() or version          # 0 while the window is still too small
+            if log:
+                log(f'version {version}: {len(window)} states in the window, {window.num_games} games')
+        if multi:
+            v = torch.tensor([version], dtype=torch.int64, device=device)
+            dist.broadcast(v, trainer_rank)
+            version = int(v.item())
+    return server, worker, trainer
