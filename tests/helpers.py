@@ -85,3 +85,25 @@ def table_eval(table):
                 v[i] = vv
         return p, v
     return fn
+
+
+def golden_net_model(case, cls):
+    """The network of a selfplay_net.json case, rebuilt the way tests/golden/make_golden.py built the
+    reference's: same seed, same constructor arguments, same randomised batch-norm statistics."""
+    import torch
+    torch.manual_seed(case['seed'] + 7)
+    m = cls(**case['net_kwargs'])
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.uniform_(-0.2, 0.2)
+            mod.running_var.uniform_(0.5, 1.5)
+            mod.weight.data.uniform_(0.5, 1.5)
+            mod.bias.data.uniform_(-0.2, 0.2)
+    return m.eval()
+
+
+def golden_net_positions(case, shape):
+    """(keys, x float32 [n, 2, H, W]) of every position the reference evaluated in that case."""
+    keys = sorted(case['evals'])
+    x = np.array([[float(c) for c in k] for k in keys], np.float32).reshape((-1,) + tuple(shape))
+    return keys, x

@@ -218,3 +218,37 @@ def test_fused_forward_is_independent_of_batch_shape(n):
         net2 = FusedC4Net.from_module(model, 'cuda')
         pa, va = net2(bb[:h].contiguous(), None)
         assert torch.equal(pa, p0[:h]) and torch.equal(va, v0[:h])
+
+
+def test_hip_networks_reproduce_the_reference_outputs():
+    """The hand-written kernels against the (p, v) the REFERENCE's networks returned while the golden
+    games were played (tests/golden/selfplay_net.json; weights rebuilt from the recorded seed):
+    fp32 kernel within 1e-5 relative, bf16 kernel within its 5e-3 tolerance."""
+    from helpers import eval_table, golden_net_model, golden_net_positions, load_json
+    from alphazero_amd import engine as E
+    from alphazero_amd.models import AlphaZeroC4
+    from alphazero_amd.net import FusedC4Net, FusedC4NetF32
+    checked = 0
+    for case in load_json('selfplay_net.json'):
+        if case['game'] != 'c4':
+            continue
+        model = golden_net_model(case, AlphaZeroC4)
+        keys, x = golden_net_positions(case, (2, 6, 7))
+        tab = eval_table(case)
+        w = (1 << (np.arange(7, dtype=np.uint64)[None, :] * np.uint64(7) + np.arange(6, dtype=np.uint64)[:, None]))
+        bb_np = np.stack([(x[:, pl].astype(np.uint64) * w[None]).sum(axis=(1, 2)) for pl in (0, 1)], axis=1)
+        bb = torch.from_numpy(bb_np.astype(np.int64)).cuda()
+        xr, valid = E.render(1, bb)
+        assert np.array_equal(xr.cpu().numpy(), x)                   # same positions as the reference rendered
+        valid = valid.cpu().numpy().astype(bool)
+        for net, rtol, atol in ((FusedC4NetF32(model, "cuda"), 1e-5, 1e-6),
+                                (FusedC4Net.from_module(model, 'cuda'), 0.0, 5e-3)):
+            p, v = net(bb, None)
+            p, v = p.cpu().numpy(), v.cpu().numpy()
+            for i, k in enumerate(keys):
+                p_ref, v_ref = tab[k]
+                assert np.allclose(p[i][valid[i]], p_ref, rtol=rtol, atol=atol), (case['net_kwargs'], i)
+                assert np.all(p[i][~valid[i]] == 0)
+                assert abs(v[i] - v_ref) <= atol + rtol * abs(v_ref)
+                checked += 1
+    assert checked > 2000

@@ -171,3 +171,25 @@ def test_model_server_and_checkpoint_format(tmp_path):
     assert load_ckpt(path, c) == 2 and torch.equal(c._cbr[0].weight, a._cbr[0].weight)
     srv.reset()
     assert srv.latest(b) == 0
+
+
+def test_mirror_networks_reproduce_the_reference_outputs():
+    """Every (p, v) the reference's own networks returned while the golden games were played
+    (alphazero/mcts.py:94-107 on alphazero/models.py, connectfour.py:31-72) against the mirror modules
+    rebuilt from the same seed: the parity chain for the HIP network kernels starts here."""
+    from helpers import eval_table, golden_net_model, golden_net_positions
+    from alphazero_amd.models import AlphaZero, AlphaZeroC4
+    for case in load_json('selfplay_net.json'):
+        c4 = case['game'] == 'c4'
+        model = golden_net_model(case, AlphaZeroC4 if c4 else AlphaZero)
+        keys, x = golden_net_positions(case, (2, 6, 7) if c4 else (2, 3, 3))
+        tab = eval_table(case)
+        occ = x[:, 0] + x[:, 1]
+        valid = (occ[:, 5, :] == 0) if c4 else (occ.reshape(len(keys), -1) == 0)    # top row / empty cells
+        with torch.no_grad():
+            logits, v = model(torch.from_numpy(x), torch.from_numpy(valid))
+        for i, k in enumerate(keys):
+            p_ref, v_ref = tab[k]
+            p = torch.softmax(logits[i][torch.from_numpy(valid[i])], 0).numpy()
+            assert p.shape == p_ref.shape and np.allclose(p, p_ref, rtol=1e-5, atol=1e-7), (case['game'], i)
+            assert abs(float(v[i, 0]) - float(v_ref)) <= 1e-6
