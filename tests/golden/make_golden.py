@@ -382,6 +382,9 @@ def main():
         play_reference_game('ttt', 'net', 32, True, 3, 32,
                             {'shape_in': [2, 3, 3], 'shape_out': [9], 'num_blocks': 1,
                              'block_channels': 4}),
+        # the shipped architecture (alphazero/config/connectfour.yaml:4-9)
+        play_reference_game('c4', 'net', 32, True, 4, 33,
+                            {'num_blocks': 6, 'channels_per_block': 32}),
     ]
     with open(os.path.join(HERE, 'selfplay_net.json'), 'w') as f:
         json.dump(net_cases, f, separators=(',', ':'))
