@@ -548,12 +548,15 @@ int az_c4net_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uint64_
                           const int32_t* leaf_info, int32_t n, float* p, float* v, void* stream) {
     if (n < 0 || num_blocks < 0 || (n && (!blob || !leaf_bb || !p || !v))) return -1;
     if (n == 0) return 0;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the large dynamic LDS size is a per-device attribute of the kernel: set once per device
+    static unsigned long long attr_done = 0;         // bit d = done on device d
+    int dev_id = 0;
+    if (hipGetDevice(&dev_id) != hipSuccess) return -2;
+    if (dev_id >= 64 || !((attr_done >> dev_id) & 1ull)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_c4net_bf16), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 LDS_BYTES) != hipSuccess)
             return -2;
-        attr_set = true;
+        if (dev_id < 64) attr_done |= 1ull << dev_id;
     }
     // one persistent workgroup per CU at most; a power of two so slots map to waves by bit masks; with
     // fewer leaves than wave slots they are spread over the CUs first (slot s = WG s % grid)

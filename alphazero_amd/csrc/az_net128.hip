@@ -474,12 +474,15 @@ int az_c4net128_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uint
     int32_t* list = leaf_info ? reinterpret_cast<int32_t*>(static_cast<uint8_t*>(workspace) + act_bytes(n)) : nullptr;
     if (list) hipLaunchKernelGGL(k_compact128, dim3(1), dim3(1024), 0, st, leaf_info, (int)n, list);
     const int lds = BIAS_OFF + 2 * CH * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the large dynamic LDS size is a per-device attribute of the kernel: set once per device
+    static unsigned long long attr_done = 0;         // bit d = done on device d
+    int dev_id = 0;
+    if (hipGetDevice(&dev_id) != hipSuccess) return -2;
+    if (dev_id >= 64 || !((attr_done >> dev_id) & 1ull)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower128), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 lds) != hipSuccess)
             return -2;
-        attr_set = true;
+        if (dev_id < 64) attr_done |= 1ull << dev_id;
     }
     const int ngroups = (n + GB - 1) / GB;
     const long stem_threads = (long)act_positions(n) * 8;

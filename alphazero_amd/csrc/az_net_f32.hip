@@ -204,12 +204,15 @@ int az_c4net_f32_forward(const float* blob, int32_t num_blocks, const uint64_t* 
     if (n < 0 || num_blocks < 0 || (n && (!blob || !leaf_bb || !p || !v))) return -1;
     if (n == 0) return 0;
     const int lds = (2 * FACT_FLOATS + 288 * 32 + 128) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the large dynamic LDS size is a per-device attribute of the kernel: set once per device
+    static unsigned long long attr_done = 0;         // bit d = done on device d
+    int dev_id = 0;
+    if (hipGetDevice(&dev_id) != hipSuccess) return -2;
+    if (dev_id >= 64 || !((attr_done >> dev_id) & 1ull)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_c4net_f32), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 lds) != hipSuccess)
             return -2;
-        attr_set = true;
+        if (dev_id < 64) attr_done |= 1ull << dev_id;
     }
     hipLaunchKernelGGL(k_c4net_f32, dim3((n + FB - 1) / FB), dim3(FTHREADS), lds, (hipStream_t)stream, blob,
                        (int)num_blocks, leaf_bb, (int)n, p, v);
