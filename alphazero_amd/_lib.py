@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(HERE, 'libazhip.so')
 GAME_TTT, GAME_C4 = 0, 1
 MAX_ACTIONS, MAX_MOVES = 9, 42
 NO_NODE = 0xFFFFFFFF
-LEAF_NONE, LEAF_EVAL, LEAF_TERMINAL, LEAF_ROOT = 0, 1, 2, 3
+LEAF_NONE, LEAF_EVAL, LEAF_TERMINAL, LEAF_ROOT, LEAF_CACHED = 0, 1, 2, 3, 4
 WINNER_NONE, WINNER_DRAW = -2, -1
 
 
@@ -53,6 +53,8 @@ SIGNATURES = {
     'az_select': (C.c_int, [_P, _P, _P, _P]),
     'az_expand_backup': (C.c_int, [_P, _P, _P, _P]),
     'az_sim_step': (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    'az_eval_cache_enable': (C.c_int, [_P, C.c_int32]),
+    'az_eval_cache_hits': (C.c_int, [_P, C.POINTER(C.c_uint64), _P]),
     'az_run_sims_uniform': (C.c_int, [_P, C.c_int32, _P]),
     'az_begin_move_uniform': (C.c_int, [_P, _P, _P]),
     'az_choose_and_advance': (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),

@@ -77,6 +77,9 @@ struct Dev {
     uint32_t        ring_cap;
     int32_t         lut_len;
     int32_t         G, cap, S, explore_depth, reuse, version;
+    uint4*          cache;      // evaluation cache: 4 x 16 B per entry, or null
+    uint32_t        cache_mask; // entries - 1
+    unsigned long long* cache_hits;   // one counter per wavefront of the search grid (no atomics)
     double          alpha, eps, c_base, c_init;
     float           one_minus_eps;
     uint64_t        seed, uid_stride, first_uid;
@@ -119,6 +122,34 @@ __device__ __forceinline__ double row16_max(double x) {
 }
 __device__ __forceinline__ double row16_sum(double x) {
     x += __shfl_xor(x, 1); x += __shfl_xor(x, 2); x += __shfl_xor(x, 4); x += __shfl_xor(x, 8);
+    return x;
+}
+
+// ---------------------------------------------------------------------------
+// evaluation cache: (position, model version) -> the evaluator's (p, v), direct-mapped, 64 B per
+// entry as four 16-byte words held by lanes 0..3 of a group:
+//   0: {nx, pv}   1: {version, v, p0, p1}   2: {p2..p5}   3: {p6, p7, p8, check}
+// Entries are written and read without locks; `check` folds the other fifteen words, so an entry
+// torn between two writers reads as a miss.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+__device__ __forceinline__ uint32_t cache_slot(uint64_t nx, uint64_t pv) {
+    uint32_t h = (uint32_t)nx * 0x9E3779B1u ^ rotl32((uint32_t)(nx >> 32) * 0x85EBCA77u, 13) ^
+                 rotl32((uint32_t)pv * 0xC2B2AE3Du, 7) ^ (uint32_t)(pv >> 32) * 0x27D4EB2Fu;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ uint32_t entry_fold(uint4 q, int sub) {
+    uint32_t h = (q.x + 0x9E3779B9u * (uint32_t)(sub + 1)) * 0x85EBCA6Bu;
+    h = (h ^ (h >> 15)) + q.y; h *= 0xC2B2AE35u;
+    h = (h ^ (h >> 13)) + q.z; h *= 0x27D4EB2Fu;
+    h = (h ^ (h >> 16)) + q.w; h *= 0x165667B1u;
+    return h ^ (h >> 15);
+}
+// xor over the four lanes of a quad
+__device__ __forceinline__ uint32_t quad_xor(uint32_t x) {
+    x ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    x ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
     return x;
 }
 
@@ -462,7 +493,8 @@ struct Grp {
 template <class GM, int GS>
 __device__ __forceinline__ void select_leaf_g(const Dev& E, const uint4* pool, uint32_t root, uint64_t& nx,
                                               uint64_t& pv, int& nm, uint32_t* path, int sub, int& kind,
-                                              int& depth, float& vterm, uint32_t& steps, uint32_t& ns_hint) {
+                                              int& depth, float& vterm, uint32_t& steps, uint32_t& ns_hint,
+                                              bool probe, uint4& cq) {
     constexpr int AS = GM::A + 1;
     static_assert(AS <= GS, "group too small for this game");
     using G_ = Grp<GS>;
@@ -501,6 +533,8 @@ __device__ __forceinline__ void select_leaf_g(const Dev& E, const uint4* pool, u
         } else if (child == AZ_NO_NODE) {                              // mcts.py:135-138
             kind = AZ_LEAF_EVAL;
             active = false;
+            // the cache line travels while the other trees of the wave finish their descent
+            if (probe && sub < 4) cq = E.cache[(size_t)(cache_slot(nx, pv) & E.cache_mask) * 4 + sub];
         } else {
             node = child;
         }
@@ -590,8 +624,24 @@ k_sim_step_p(Dev E, const float* p, const float* v, uint64_t* leaf_bb, int32_t* 
     int nm = (int)h2.z, kind = (int)h3.x;
     uint32_t sims = 0, evals = 0, steps = 0;
 
-    if (DO_EXPAND && kind == AZ_LEAF_EVAL) {
+    if (DO_EXPAND && (kind == AZ_LEAF_EVAL || kind == AZ_LEAF_CACHED)) {
         const int depth = (int)h3.y;
+        if (E.cache && kind == AZ_LEAF_EVAL) {                       // remember what the evaluator said
+            const int w0 = 4 * sub - 6;                              // index into p of this lane's word .x
+            uint32_t w[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int a = w0 + c;
+                const uint32_t t = G_::bcast(__float_as_uint(p_lane), a & (GS - 1));
+                w[c] = (a >= 0 && a < GM::A) ? t : 0u;
+            }
+            uint4 q = make_uint4(w[0], w[1], w[2], w[3]);
+            if (sub == 0) q = make_uint4((uint32_t)leaf_nx, (uint32_t)(leaf_nx >> 32), (uint32_t)leaf_pv, (uint32_t)(leaf_pv >> 32));
+            if (sub == 1) { q.x = (uint32_t)E.version; q.y = __float_as_uint(v_g); }
+            const uint32_t chk = quad_xor(sub < 4 ? entry_fold(q, sub) : 0u);
+            if (sub == 3) q.w = chk;
+            if (sub < 4) E.cache[(size_t)(cache_slot(leaf_nx, leaf_pv) & E.cache_mask) * 4 + sub] = q;
+        }
         // mcts.py:20-26: the new node, priors compacted to the legal moves
         uint32_t idx = AZ_NO_NODE;
         if (alloc < (uint32_t)E.cap) { idx = alloc; alloc += 1; } else err |= 1u;
@@ -627,12 +677,44 @@ k_sim_step_p(Dev E, const float* p, const float* v, uint64_t* leaf_bb, int32_t* 
     int depth = 0;
     if (DO_SELECT) {
         float vterm;
-        select_leaf_g<GM, GS>(E, pool, root, nx, pv, nm, path, sub, kind, depth, vterm, steps, root_ns);
+        uint4 cq = make_uint4(0u, 0u, 0u, 0u);
+        const bool probe = DO_EXPAND && E.cache != nullptr;
+        select_leaf_g<GM, GS>(E, pool, root, nx, pv, nm, path, sub, kind, depth, vterm, steps, root_ns, probe, cq);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // path[] is written by lane 0 of the group
+        if (DO_EXPAND && probe) {
+            bool hit = false;
+            if (kind == AZ_LEAF_EVAL) {
+                uint4 f = cq;
+                if (sub == 3) f.w = 0u;
+                const uint32_t chk = quad_xor(sub < 4 ? entry_fold(f, sub) : 0u);
+                bool ok = true;
+                if (sub == 0) ok = cq.x == (uint32_t)nx && cq.y == (uint32_t)(nx >> 32) && cq.z == (uint32_t)pv && cq.w == (uint32_t)(pv >> 32);
+                if (sub == 1) ok = cq.x == (uint32_t)E.version;
+                if (sub == 3) ok = cq.w == chk;
+                hit = (G_::gballot(ok) & 0xFu) == 0xFu;
+                if (hit) {
+                    // this position was evaluated before with these weights: the evaluator's row is
+                    // filled in here and the evaluator skips it
+                    const int wi = 6 + sub, src = (wi >> 2) & 3;
+                    const uint32_t t0 = G_::bcast(cq.x, src), t1 = G_::bcast(cq.y, src);
+                    const uint32_t t2 = G_::bcast(cq.z, src), t3 = G_::bcast(cq.w, src);
+                    const uint32_t vb = G_::bcast(cq.y, 1);
+                    const uint32_t pw = (wi & 2) ? ((wi & 1) ? t3 : t2) : ((wi & 1) ? t1 : t0);
+                    if (sub < GM::A) const_cast<float*>(p)[(size_t)g * GM::A + sub] = __uint_as_float(pw);
+                    if (sub == 0) const_cast<float*>(v)[g] = __uint_as_float(vb);
+                    kind = AZ_LEAF_CACHED;
+                }
+            }
+            const unsigned long long hm = __ballot(hit && sub == 0);
+            if (hm && lane == 0) {
+                unsigned long long* hc = E.cache_hits + (size_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+                *hc += (unsigned long long)__popcll(hm);
+            }
+        }
         if (kind == AZ_LEAF_TERMINAL) {
             backup_g<GM, GS>(pool, depth, path, vterm, sub);
             sims += 1;
-        } else if (kind == AZ_LEAF_EVAL) {
+        } else if (kind == AZ_LEAF_EVAL || kind == AZ_LEAF_CACHED) {
             for (int d = sub; d < depth; d += GS) s->path[d] = path[d];
         }
         if (sub == 0) {
@@ -668,7 +750,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_run_uniform_p(Dev E, int num_
         uint64_t nx = nx0, pv = pv0;
         int nm = nm0, depth, kind;
         float vterm;
-        select_leaf_g<GM, GS>(E, pool, root, nx, pv, nm, path, sub, kind, depth, vterm, steps, root_ns);
+        uint4 cq_unused;
+        select_leaf_g<GM, GS>(E, pool, root, nx, pv, nm, path, sub, kind, depth, vterm, steps, root_ns, false, cq_unused);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         if (kind == AZ_LEAF_EVAL) {
             const uint32_t idx = expand_node_g<GM, GS>(E, pool, alloc, nx, pv, nullptr, err, sub);
@@ -901,7 +984,7 @@ int az_engine_destroy(az_engine* e) {
     if (!e) return 0;
     (void)hipSetDevice(e->cfg.device);
     (void)hipFree(e->d.pool); (void)hipFree(e->d.slots); (void)hipFree(e->d.rec_visits); (void)hipFree(e->d.ring);
-    (void)hipFree(e->d.ring_count); (void)hipFree(e->lut_dev);
+    (void)hipFree(e->d.ring_count); (void)hipFree(e->lut_dev); (void)hipFree(e->d.cache); (void)hipFree(e->d.cache_hits);
     delete e;
     return 0;
 }
@@ -929,6 +1012,39 @@ int az_set_puct_lut(az_engine* e, const double* lut_host, int32_t n) {
 int az_set_model_version(az_engine* e, int32_t version) {
     if (!e) return fail("null engine");
     e->d.version = version; e->cfg.model_version = version;
+    return 0;
+}
+
+int az_eval_cache_enable(az_engine* e, int32_t log2_entries) {
+    if (!e) return fail("null engine");
+    if (log2_entries != 0 && (log2_entries < 10 || log2_entries > 28)) return fail("eval cache: log2_entries must be 0 or 10..28");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(hipDeviceSynchronize());
+    (void)hipFree(e->d.cache); (void)hipFree(e->d.cache_hits);
+    e->d.cache = nullptr; e->d.cache_mask = 0; e->d.cache_hits = nullptr;
+    if (log2_entries == 0) return 0;
+    const size_t bytes = ((size_t)1 << log2_entries) * 64;
+    const size_t counters = (size_t)e->d.G + WAVES_PER_BLOCK;       // >= wavefronts of any search grid
+    uint4* t = nullptr;
+    unsigned long long* c = nullptr;
+    hipError_t err = hipMalloc(&t, bytes);
+    if (err == hipSuccess) err = hipMalloc(&c, counters * 8);
+    if (err != hipSuccess) { (void)hipFree(t); return fail("hipMalloc (evaluation cache)", err); }
+    HIPCHK(hipMemset(t, 0, bytes));
+    HIPCHK(hipMemset(c, 0, counters * 8));
+    HIPCHK(hipDeviceSynchronize());
+    e->d.cache = t; e->d.cache_mask = (uint32_t)(((size_t)1 << log2_entries) - 1); e->d.cache_hits = c;
+    return 0;
+}
+
+int az_eval_cache_hits(az_engine* e, uint64_t* hits, void* stream) {
+    if (!e || !hits) return fail("null argument");
+    *hits = 0;
+    if (!e->d.cache_hits) return 0;
+    std::vector<unsigned long long> h((size_t)e->d.G + WAVES_PER_BLOCK);
+    HIPCHK(hipMemcpyAsync(h.data(), e->d.cache_hits, h.size() * 8, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    for (unsigned long long x : h) *hits += x;
     return 0;
 }
 
@@ -982,7 +1098,7 @@ int az_expand_backup(az_engine* e, const float* p, const float* v, void* stream)
     return 0;
 }
 
-int az_sim_step(az_engine* e, const float* p, const float* v, uint64_t* leaf_bb, int32_t* leaf_info, void* stream) {
+int az_sim_step(az_engine* e, float* p, float* v, uint64_t* leaf_bb, int32_t* leaf_info, void* stream) {
     if (!e || !leaf_bb || !leaf_info) return fail("null argument");
     if (!p) return az_select(e, leaf_bb, leaf_info, stream);
     if (!v) return fail("v is required with p");

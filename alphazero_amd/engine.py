@@ -85,6 +85,18 @@ class SelfPlayEngine:
     def reset_games(self):
         check(self.lib.az_reset_games(self.h, _stream()))
 
+    def enable_eval_cache(self, log2_entries):
+        """Device table of 2**log2_entries evaluator outputs keyed by (position, model version); 0
+        turns it off.  sim_step then answers repeated leaves itself (LEAF_CACHED) and writes their rows
+        of p and v.  Only for evaluators whose rows are pure functions of the position (the one-launch
+        HIP networks are); the reference has no such cache (alphazero/mcts.py:139-142)."""
+        check(self.lib.az_eval_cache_enable(self.h, int(log2_entries)))
+
+    def eval_cache_hits(self):
+        n = C.c_uint64()
+        check(self.lib.az_eval_cache_hits(self.h, C.byref(n), _stream()))
+        return int(n.value)
+
     # ---- one move, lock-step ---------------------------------------------------
     def begin_move(self):
         check(self.lib.az_begin_move(self.h, ptr(self.leaf_bb), ptr(self.leaf_info), _stream()))

@@ -28,7 +28,7 @@ def record_to_game(game_cls, rec):
 
 class SelfPlayWorker:
     def __init__(self, config, model_server, dataset, device, num_games=1024, seed=0,
-                 rank=0, world_size=1, evaluator=None):
+                 rank=0, world_size=1, evaluator=None, eval_cache_log2=0):
         self._config = config
         self._model_server = model_server
         self._dataset = dataset
@@ -55,6 +55,13 @@ class SelfPlayWorker:
                 self._fused = FusedC4Net.from_module(self._model, self._device)
             elif isinstance(self._model, AlphaZeroC4) and self._model.block_channels == 128:
                 self._fused = C4Net128(self._model, self._device, max_leaves=self.num_games)
+        if eval_cache_log2:
+            # leaves whose position was already evaluated under the current model version are answered
+            # by the engine; sound only for evaluators that are pure, batch-independent functions of
+            # the position, which the HIP networks are and a torch module in general is not
+            if self._fused is None and evaluator is None:
+                raise ValueError('eval_cache_log2 needs one of the HIP networks (or a caller-supplied evaluator)')
+            self.engine.enable_eval_cache(eval_cache_log2)
         self._version = 0
         self.positions = 0
         self.games_finished = 0

@@ -131,6 +131,10 @@ def main():
                          'long-running job has them (cheap: ~12 ms per move)')
     ap.add_argument('--node-capacity', type=int, default=0, help='nodes per game pool (0 = never-free bound)')
     ap.add_argument('--allow-pool-errors', action='store_true', help='tuning only')
+    ap.add_argument('--eval-cache-log2', type=int, default=0,
+                    help='log2 entries of the engine evaluation cache (0 = off, the default: every leaf goes '
+                         'through the network as in the reference); the cache is invalidated every step, as '
+                         'a weight update per move would')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     args = ap.parse_args()
@@ -172,6 +176,10 @@ def main():
         else:
             evaluate = lambda bb, info: evaluate_leaves(eng.game, net, bb, info)
 
+    use_cache = args.eval_cache_log2 > 0 and net is not None and args.net_impl == 'hip'
+    if use_cache:
+        eng.enable_eval_cache(args.eval_cache_log2)
+    step_no = [0]
     net_ev, tree_ev = [], []       # (start, end) HIP event pairs on the launch stream
 
     def timed(fn, sink, on):
@@ -195,6 +203,9 @@ def main():
                 broadcast_model(net, 1, src=0)
                 if args.net_impl == 'hip':
                     fused.load_module(net)
+            if use_cache:
+                step_no[0] += 1
+                eng.set_model_version(step_no[0])       # nothing cached under earlier weights is used
             bb, info = eng.begin_move()
             p, _ = evaluate(bb, info)
             eng.apply_root(p)
@@ -233,6 +244,7 @@ def main():
         one_step(False)
     eng.drain_finished()
     st0 = eng.stats()
+    hits0 = eng.eval_cache_hits() if use_cache else 0
     sync_all()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -240,6 +252,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     st1 = eng.stats()
+    hits = (eng.eval_cache_hits() - hits0) if use_cache else 0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -270,6 +283,8 @@ def main():
                    'net_impl': None if net is None else args.net_impl, 'preroll_moves': args.preroll,
                    'mix_moves': args.mix_moves,
                    'mean_select_depth': d, 'leaf_eval_fraction': f,
+                   'eval_cache_log2': args.eval_cache_log2 if use_cache else 0,
+                   'eval_cache_hit_rate': hits / max(evals, 1),
                    'games_finished': st1['games'] - st0['games']},
     }
     if rank == 0:
@@ -292,14 +307,15 @@ def main():
             ms = avg_ms(net_ev)
             # leaves one launch evaluates x flops per leaf; the 128-channel kernels take every leaf of
             # the batch, needed or not, and only the needed ones count as algorithmic work
-            fl = trunk_flops_per_leaf(blocks, ch) * f * G
+            f_net = (evals - hits) / max(sims, 1)          # leaves that reach the network
+            fl = trunk_flops_per_leaf(blocks, ch) * f_net * G
             tf = fl / (ms * 1e-3) / 1e12
             kname = 'k_c4net_bf16' if ch <= 32 else 'k_stem128 + k_tower128 + k_heads128'
             out['roofline'] = {'kernel': kname, 'bound': 'mfma', 'achieved': tf, 'peak': BF16_PEAK_TFLOPS,
                                'unit': 'TFLOP/s', 'frac': tf / BF16_PEAK_TFLOPS,
                                'traffic': pmc_traffic('k_c4net_bf16') if ch <= 32 else None,
                                'avg_launch_ms': ms, 'flops_per_leaf': trunk_flops_per_leaf(blocks, ch),
-                               'leaves_per_launch': f * G}
+                               'leaves_per_launch': f_net * G}
             ms = avg_ms(tree_ev)
             gbs = bps * G / (ms * 1e-3) / 1e9
             out['roofline_tree'] = {'kernel': 'k_sim_step<GameC4,true,true>', 'bound': 'hbm', 'achieved': gbs,

@@ -43,6 +43,9 @@ extern "C" {
 #define AZ_LEAF_EVAL     1  /* un-expanded non-terminal leaf: needs (p, v)   */
 #define AZ_LEAF_TERMINAL 2  /* terminal leaf: valued by the rules            */
 #define AZ_LEAF_ROOT     3  /* un-expanded search root: needs p (v unused)   */
+#define AZ_LEAF_CACHED   4  /* un-expanded leaf whose (p, v) az_sim_step found
+                               in the evaluation cache and wrote to rows g of
+                               p and v itself: the evaluator leaves it alone  */
 
 #define AZ_WINNER_NONE (-2)
 #define AZ_WINNER_DRAW (-1)
@@ -119,9 +122,22 @@ int  az_begin_move(az_engine* e, uint64_t* leaf_bb, int32_t* leaf_info, void* st
 int  az_apply_root(az_engine* e, const float* p, const double* eta, void* stream);
 int  az_select(az_engine* e, uint64_t* leaf_bb, int32_t* leaf_info, void* stream);
 int  az_expand_backup(az_engine* e, const float* p, const float* v, void* stream);
-/* fused az_expand_backup (if p != NULL) followed by az_select               */
-int  az_sim_step(az_engine* e, const float* p, const float* v,
+/* fused az_expand_backup (if p != NULL) followed by az_select.  With the
+ * evaluation cache enabled rows of p and v are also WRITTEN (AZ_LEAF_CACHED) */
+int  az_sim_step(az_engine* e, float* p, float* v,
                  uint64_t* leaf_bb, int32_t* leaf_info, void* stream);
+/* Evaluation cache (no counterpart in the reference, which evaluates every
+ * leaf: mcts.py:139-142).  A direct-mapped table of 2^log2_entries 64-byte
+ * entries in device memory, keyed by the leaf position and the model version:
+ * az_expand_backup / az_sim_step record the (p, v) they are given for an
+ * AZ_LEAF_EVAL leaf, and az_sim_step answers a later leaf with the same
+ * position and version from the table (AZ_LEAF_CACHED).  Only for evaluators
+ * that are pure functions of the position whose rows do not depend on the
+ * rest of the batch; az_set_model_version invalidates.  log2_entries 0 turns
+ * it off and frees the table.  Synchronous.                                  */
+int  az_eval_cache_enable(az_engine* e, int32_t log2_entries);
+/* leaves answered from the cache since it was enabled.  Synchronous.         */
+int  az_eval_cache_hits(az_engine* e, uint64_t* hits, void* stream);
 /* num_sims simulations per game inside ONE launch with the UniformModel
  * evaluated in place (models.py:90-95: p = 1/n_legal, v = 0)                */
 int  az_run_sims_uniform(az_engine* e, int32_t num_sims, void* stream);
