@@ -10,6 +10,34 @@ def _line(b):
     return any((b & m) == m for m in _LINES)
 
 
+_SOLVED = {}
+
+
+def _minimax(p0, p1, root_player):
+    """Game-theoretic score of the position for `root_player`, with the reference's scale
+    (alphazero/games/tictactoe.py:87-111): outcome (+1, 0, -1) times 5 - moves // 2, so quicker wins
+    and slower losses score higher.  Returns (score, scores of the legal moves in ascending order)."""
+    key = (p0, p1, root_player)
+    hit = _SOLVED.get(key)
+    if hit is not None:
+        return hit
+    n = bin(p0 | p1).count('1')
+    won0, won1 = _line(p0), _line(p1)
+    if n >= 5 and (won0 or won1 or n == 9):
+        w = 0 if won0 else 1 if won1 else -1
+        res = ((5 - n // 2) * (0 if w < 0 else 1 if w == root_player else -1), [])
+    else:
+        mover = n & 1
+        scores = []
+        for a in range(9):
+            if not ((p0 | p1) >> a) & 1:
+                scores.append(_minimax(p0 | (1 << a), p1, root_player)[0] if mover == 0 else
+                              _minimax(p0, p1 | (1 << a), root_player)[0])
+        res = (max(scores) if mover == root_player else min(scores), scores)
+    _SOLVED[key] = res
+    return res
+
+
 class TicTacToe(Game):
     NUM_ACTIONS = 9
     AZ_GAME_ID = 0
@@ -60,6 +88,15 @@ class TicTacToe(Game):
         img[0, hist[self.next_player::2]] = 1
         img[1, hist[self.prev_player::2]] = 1
         return img.reshape(2, 3, 3)
+
+    def solve(self):
+        """(score of every legal move, game value in {-1, 0, 1}) for the player to move
+        (alphazero/games/tictactoe.py:74-117)."""
+        n = len(self.history)
+        nx, pv, _ = self.position()
+        p0, p1 = (pv, nx) if n & 1 else (nx, pv)
+        s, scores = _minimax(p0, p1, n & 1)
+        return list(scores), (1 if s > 0 else -1 if s < 0 else 0)
 
     def __str__(self):
         h = self.history

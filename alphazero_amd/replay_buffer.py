@@ -1,14 +1,108 @@
-"""Replay window with the reference's sample layout (alphazero/replay_buffer.py:105-195).
+"""Replay storage with the reference's sample layout and on-disk format
+(alphazero/replay_buffer.py:9-195).
 
-`ReplayBufferDataset.add_game(game, version)` and `dataset[i]` behave like the reference's
-SQLite-backed dataset, but the store is an in-memory list of finished games (histories and
-int16 visit counts, exactly what the reference serialises, replay_buffer.py:30-35); the on-disk
-SQLite schema is reproduced by `write_sqlite` so existing tooling can read a dump.
+`SelfPlayDatabase` reads and writes the reference's SQLite schema row for row (tables
+`selfplay_games` and `game_states`, history as comma-separated text, visit counts as one int16
+blob), so databases written by either side open in the other.  `ReplayBufferDataset.add_game` and
+`dataset[i]` behave like the reference's dataset; games are kept in memory for sampling and, when
+a path is given, also appended to the database (and loaded from it on open).  `RecordSink` moves
+the database writes of a self-play loop onto a background thread: it takes the engine's raw
+finished-game records and writes them as rows.  `DeviceReplayWindow` is the training window held
+on the GPU.
 """
+import os
+import queue
 import sqlite3
+import threading
 
 import numpy as np
 from torch.utils.data import Dataset, Sampler
+
+_SCHEMA = (
+    """CREATE TABLE IF NOT EXISTS selfplay_games (
+            id INTEGER PRIMARY KEY AUTOINCREMENT NOT NULL,
+            model_version INTEGER NOT NULL,
+            history TEXT NOT NULL,
+            search_statistics BLOB NOT NULL);""",
+    """CREATE TABLE IF NOT EXISTS game_states (
+            id INTEGER PRIMARY KEY AUTOINCREMENT NOT NULL,
+            game_id INTEGER NOT NULL,
+            move_index INTEGER NOT NULL);""",
+)
+
+
+def _encode_game(history, stats):
+    """(history text, int16 blob) as the reference stores them (replay_buffer.py:30-35); counts
+    above 32767 wrap exactly as its astype(int16) does."""
+    text = ','.join(str(int(a)) for a in history)
+    blob = np.concatenate([np.asarray(s) for s in stats]).astype(np.int16).tobytes()
+    return text, blob
+
+
+class SelfPlayDatabase:
+    """The reference's two tables behind its method names (replay_buffer.py:9-87)."""
+
+    def __init__(self, dbpath):
+        self._con = sqlite3.connect(dbpath)
+
+    @staticmethod
+    def connect(dbpath):
+        return SelfPlayDatabase(dbpath)
+
+    def close(self):
+        self._con.close()
+
+    def init_db(self):
+        for stmt in _SCHEMA:
+            self._con.execute(stmt)
+        self._con.commit()
+
+    def write_rows(self, rows):
+        """rows: iterable of (model_version, history list, per-move visit arrays); one commit."""
+        for version, history, stats in rows:
+            text, blob = _encode_game(history, stats)
+            cur = self._con.execute('INSERT INTO selfplay_games (model_version, history, search_statistics) '
+                                    'VALUES (?, ?, ?);', (int(version), text, blob))
+            gid = cur.lastrowid
+            self._con.executemany('INSERT INTO game_states (game_id, move_index) VALUES (?, ?);',
+                                  [(gid, m) for m in range(len(history))])
+        self._con.commit()
+
+    def write_game(self, game, model_version):
+        assert len(game.search_statistics) == len(game.history)
+        assert game.terminal
+        assert game.search_statistics[0] is not None
+        self.write_rows([(model_version, game.history, game.search_statistics)])
+
+    def read_game(self, i, game):
+        assert len(game.history) == 0
+        row = self._con.execute('SELECT model_version, history, search_statistics FROM selfplay_games '
+                                'WHERE id = ?;', (i + 1,)).fetchone()
+        if row is None:
+            raise ValueError
+        version, text, blob = row
+        counts = np.frombuffer(blob, dtype=np.int16)
+        n = 0
+        for a in (int(t) for t in text.split(',')):
+            k = len(game.valid_actions)
+            game.take_action(a, counts[n:n + k])
+            n += k
+        return game, version
+
+    def read_state(self, i):
+        row = self._con.execute('SELECT game_id, move_index FROM game_states WHERE id = ?;', (i + 1,)).fetchone()
+        if row is None:
+            raise ValueError
+        return row[0] - 1, row[1]
+
+    def num_games(self):
+        return self._con.execute('SELECT COUNT(*) FROM selfplay_games;').fetchone()[0]
+
+    def num_states(self):
+        return self._con.execute('SELECT COUNT(*) FROM game_states;').fetchone()[0]
+
+    def num_distinct_games(self):
+        return self._con.execute('SELECT COUNT(DISTINCT history) FROM selfplay_games;').fetchone()[0]
 
 
 class ReplayBufferDataset(Dataset):
@@ -17,6 +111,19 @@ class ReplayBufferDataset(Dataset):
         self._games = []          # (history list, [int16 visits per move], model_version)
         self._states = []         # (game_index, move_index)
         self._dbpath = dbpath
+        self._db = None
+        if dbpath is not None:
+            self._db = SelfPlayDatabase.connect(dbpath)
+            self._db.init_db()
+            self._pid = os.getpid()
+            for i in range(self._db.num_games()):            # an existing database is the window's start
+                g, version = self._db.read_game(i, config.Game())
+                self._remember(g.history, g.search_statistics, version)
+
+    def _remember(self, history, stats, version):
+        gi = len(self._games)
+        self._games.append((list(history), [np.asarray(s).astype(np.int16) for s in stats], int(version)))
+        self._states.extend((gi, m) for m in range(len(history)))
 
     def __len__(self):
         return len(self._states)
@@ -25,10 +132,11 @@ class ReplayBufferDataset(Dataset):
         assert game.terminal
         assert len(game.search_statistics) == len(game.history)
         assert game.search_statistics[0] is not None
-        stats = [np.asarray(s).astype(np.int16) for s in game.search_statistics]
-        gi = len(self._games)
-        self._games.append((list(game.history), stats, int(model_version)))
-        self._states.extend((gi, m) for m in range(len(game.history)))
+        self._remember(game.history, game.search_statistics, model_version)
+        if self._db is not None:
+            if os.getpid() != self._pid:                     # SQLite connections do not survive a fork
+                self._db, self._pid = SelfPlayDatabase.connect(self._dbpath), os.getpid()
+            self._db.write_game(game, model_version)
 
     def num_games(self):
         return len(self._games)
@@ -64,19 +172,60 @@ class ReplayBufferDataset(Dataset):
                 'v*': v_star, 'move_scores': scores}
 
     def write_sqlite(self, path):
-        """Dump in the reference's schema (replay_buffer.py:15-47)."""
-        con = sqlite3.connect(path)
-        con.execute('CREATE TABLE IF NOT EXISTS selfplay_games (id INTEGER PRIMARY KEY AUTOINCREMENT NOT NULL,'
-                    ' model_version INTEGER NOT NULL, history TEXT NOT NULL, search_statistics BLOB NOT NULL);')
-        con.execute('CREATE TABLE IF NOT EXISTS game_states (id INTEGER PRIMARY KEY AUTOINCREMENT NOT NULL,'
-                    ' game_id INTEGER NOT NULL, move_index INTEGER NOT NULL);')
-        for hist, stats, version in self._games:
-            cur = con.execute('INSERT INTO selfplay_games (model_version, history, search_statistics) VALUES (?,?,?);',
-                              (version, ','.join(str(a) for a in hist), np.concatenate(stats).tobytes()))
-            con.executemany('INSERT INTO game_states (game_id, move_index) VALUES (?,?);',
-                            [(cur.lastrowid, m) for m in range(len(hist))])
-        con.commit()
-        con.close()
+        """Dump every game held in memory to a new database in the reference's schema."""
+        db = SelfPlayDatabase.connect(path)
+        db.init_db()
+        db.write_rows((version, hist, stats) for hist, stats, version in self._games)
+        db.close()
+
+
+class RecordSink:
+    """Background writer from raw az_game_record bytes to the reference's SQLite tables, so a
+    self-play loop never waits on a commit (the reference commits once per game inside play_game:
+    selfplay.py:41, replay_buffer.py:40-47).  `put(raw)` takes the uint8 [n, record size] array of
+    SelfPlayEngine.drain_finished_bytes (copied); `close()` drains the queue and joins."""
+
+    def __init__(self, dbpath):
+        from ._lib import GameRecord
+        self._rec = GameRecord
+        self._q = queue.Queue()
+        self._error = None
+        self.games_written = 0
+        self._thread = threading.Thread(target=self._run, args=(dbpath,), daemon=True)
+        self._thread.start()
+
+    def _run(self, dbpath):
+        try:
+            db = SelfPlayDatabase.connect(dbpath)
+            db.init_db()
+            while True:
+                raw = self._q.get()
+                if raw is None:
+                    break
+                rows = []
+                for i in range(raw.shape[0]):
+                    r = self._rec.from_buffer_copy(raw[i].tobytes())
+                    n = r.num_moves
+                    rows.append((r.model_version, [int(r.history[m]) for m in range(n)],
+                                 [np.array(r.visits[m][:r.num_edges[m]], dtype=np.uint32) for m in range(n)]))
+                db.write_rows(rows)
+                self.games_written += len(rows)
+            db.close()
+        except Exception as e:                               # surfaced by put()/close()
+            self._error = e
+
+    def put(self, raw):
+        if self._error is not None:
+            raise self._error
+        raw = np.array(raw, dtype=np.uint8, copy=True)
+        if raw.shape[0]:
+            self._q.put(raw)
+
+    def close(self):
+        self._q.put(None)
+        self._thread.join()
+        if self._error is not None:
+            raise self._error
 
 
 class ReplayBufferSampler(Sampler):

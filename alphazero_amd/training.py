@@ -4,10 +4,13 @@ cross-entropy + MSE, weights published after every step.  Host-side torch code; 
 writer and model server are duck-typed (`add_scalar`, `update(model, version)`).  `dataset` is a
 ReplayBufferDataset (the reference's per-state sample dicts) or a DeviceReplayWindow (batches taken
 straight from tensors on the GPU)."""
+import numpy as np
 import torch
+import torch.nn.functional as F
 from torch.optim import SGD
 from torch.optim.lr_scheduler import MultiStepLR
 
+from .loss import masked_cross_entropy, masked_kl_div
 from .replay_buffer import ReplayBufferSampler
 
 
@@ -33,10 +36,35 @@ class TrainingWorker:
             # DeviceReplayWindow: the window already lives on the GPU as tensors
             b = self._dataset.sample(self._config.training['batch_size'])
             return (b['x'].to(self._device), b['p'].to(self._device), b['z'].to(self._device),
-                    b['p_valid'].to(self._device))
+                    b['p_valid'].to(self._device), None)
         items = [self._dataset[i] for i in next(self._sampler)]
-        stack = lambda k, dt: torch.as_tensor(__import__('numpy').stack([it[k] for it in items])).to(self._device, dt)
-        return stack('x', torch.float32), stack('p', torch.float32), stack('z', torch.float32), stack('p_valid', torch.bool)
+        stack = lambda k, dt: torch.as_tensor(np.stack([it[k] for it in items])).to(self._device, dt)
+        solved = torch.as_tensor([bool(it['solved']) for it in items])
+        extra = None
+        if bool(solved.any()):
+            extra = {'solved': solved.to(self._device), 'v*': stack('v*', torch.float32),
+                     'move_scores': stack('move_scores', torch.float32)}
+        return (stack('x', torch.float32), stack('p', torch.float32), stack('z', torch.float32),
+                stack('p_valid', torch.bool), extra)
+
+    def _log_solved(self, extra, p, z, p_hat, v_hat, p_valid, it):
+        """Distance of the search targets and of the predictions from the solver's answers on the
+        solved states of the batch (alphazero/training.py:85-113)."""
+        w = self._writer
+        with torch.no_grad():
+            solved = extra['solved']
+            v_star = extra['v*'][solved]
+            scores = extra['move_scores'][solved].clone()
+            scores[~p_valid[solved]] = -float('inf')
+            p_star = F.softmax(scores, dim=1)
+            logp = torch.log(p)
+            w.add_scalar('eval/policy_target_KL', masked_kl_div(logp[solved], p_star, p_valid[solved]).mean(), it)
+            w.add_scalar('eval/policy_prediction_KL', masked_kl_div(p_hat[solved], p_star, p_valid[solved]).mean(), it)
+            w.add_scalar('eval/value_target_mse', ((v_star - z[solved]) ** 2).mean(), it)
+            w.add_scalar('eval/value_prediction_mse', ((v_star - v_hat[solved]) ** 2).mean(), it)
+            w.add_scalar('eval/policy_target_entropy', masked_cross_entropy(logp, p, p_valid).mean(), it)
+            w.add_scalar('eval/policy_prediction_entropy',
+                         masked_cross_entropy(p_hat, F.softmax(p_hat, dim=1), p_valid).mean(), it)
 
     def process_batch(self):
         N, B = len(self._dataset), self._config.training['batch_size']
@@ -45,7 +73,7 @@ class TrainingWorker:
             print(f'Skipping batch, too few examples in replay buffer ({N} < {M}).')
             return 0
         self._model.train()
-        x, p, z, p_valid = self._batch()
+        x, p, z, p_valid, extra = self._batch()
         p_hat, v_hat = self._model(x, p_valid)
         policy_loss, value_loss = self._loss(p, z, p_hat, v_hat, p_valid)
         self._optimizer.zero_grad()
@@ -61,4 +89,11 @@ class TrainingWorker:
             self._writer.add_scalar('loss/value', value_loss, it)
             self._writer.add_scalar('loss/total', total, it)
             self._writer.add_scalar('optim/learning_rate', self._lr_schedule.get_last_lr()[0], it)
+            if extra is not None:
+                self._log_solved(extra, p, z, p_hat, v_hat, p_valid, it)
+            db = getattr(self._dataset, 'db', None)
+            if db is not None:                                     # training.py:117-123
+                self._writer.add_scalar('data/total_games', db.num_games(), it)
+                self._writer.add_scalar('data/distinct_games', db.num_distinct_games(), it)
+                self._writer.add_scalar('data/total_states', db.num_states(), it)
         return it + 1

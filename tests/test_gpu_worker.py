@@ -204,3 +204,56 @@ def test_synchronous_play_and_train_loop():
     assert worker.engine.stats()['errors'] == 0 and worker.games_finished > 0
     for a, b in zip(worker._model.state_dict().values(), trainer.model.state_dict().values()):
         assert torch.equal(a, b)
+
+
+def test_match_play_against_the_solver_and_solver_metrics(tmp_path):
+    """alphazero/eval.py:40-132 on the GPU search: the tree follows the game through both players'
+    moves; a perfect opponent is never beaten.  Then the self-play worker's games go through the
+    SQLite dataset into a training step that logs the solver metrics (alphazero/training.py:85-123)."""
+    from alphazero_amd.eval import AlphaZeroPlayer, SolverPlayer, match
+    from alphazero_amd.games import TicTacToe
+    from alphazero_amd.models import UniformModel
+    from alphazero_amd.replay_buffer import ReplayBufferDataset
+    from alphazero_amd.selfplay import SelfPlayWorker
+    from alphazero_amd.training import TrainingWorker
+    np.random.seed(2)
+    az = AlphaZeroPlayer(UniformModel(), num_simulations=96)
+    wins_az, draws, wins_solver = match(TicTacToe, [az, SolverPlayer()], 4)
+    assert wins_az == 0 and wins_az + draws + wins_solver == 4
+
+    cfg = _config({'module': 'alphazero.games.tictactoe', 'name': 'TicTacToe'},
+                  {'module': 'alphazero.models', 'name': 'AlphaZero',
+                   'kwargs': {'shape_in': [2, 3, 3], 'shape_out': [9], 'num_blocks': 1, 'block_channels': 4}},
+                  S=16, depth=3)
+    cfg._conf['loss'] = {'module': 'alphazero.loss', 'name': 'AlphaZeroLoss'}
+    cfg._conf['training'] = {'lr': 0.05, 'momentum': 0.9, 'weight_decay': 1e-4, 'lr_schedule': [100],
+                             'lr_schedule_gamma': 0.1, 'batch_size': 32}
+    path = str(tmp_path / 'selfplay.sqlite')
+    ds = ReplayBufferDataset(cfg, path)
+    worker = SelfPlayWorker(cfg, _Server(0), ds, 'cuda:0', num_games=32, seed=4)
+    while len(ds) < 64:
+        worker.play_game()
+    assert ds.num_games() == len(ReplayBufferDataset(cfg, path)._games)        # every game reached the file
+
+    class _Writer:
+        def __init__(self):
+            self.tags = {}
+
+        def add_scalar(self, tag, value, step):
+            self.tags[tag] = float(value)
+
+    class _Pub:
+        def update(self, model, version):
+            self.version = version
+
+    w = _Writer()
+    np.random.seed(0)
+    torch.manual_seed(0)
+    tw = TrainingWorker(cfg, _Pub(), ds, w, 'cuda')
+    assert tw.process_batch() == 1
+    for tag in ('loss/policy', 'loss/value', 'loss/total', 'optim/learning_rate', 'eval/policy_target_KL',
+                'eval/policy_prediction_KL', 'eval/value_target_mse', 'eval/value_prediction_mse',
+                'eval/policy_target_entropy', 'eval/policy_prediction_entropy', 'data/total_games',
+                'data/distinct_games', 'data/total_states'):
+        assert tag in w.tags and np.isfinite(w.tags[tag]), tag
+    assert w.tags['data/total_states'] == len(ds) and w.tags['eval/policy_target_KL'] >= 0

@@ -3,6 +3,7 @@ numerics vs goldens, model/state_dict layout, config loader, losses, replay wind
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from helpers import load_json, unhex
@@ -193,3 +194,104 @@ def test_mirror_networks_reproduce_the_reference_outputs():
             p = torch.softmax(logits[i][torch.from_numpy(valid[i])], 0).numpy()
             assert p.shape == p_ref.shape and np.allclose(p, p_ref, rtol=1e-5, atol=1e-7), (case['game'], i)
             assert abs(float(v[i, 0]) - float(v_ref)) <= 1e-6
+
+
+def _host_cfg(name):
+    from alphazero_amd.config import AlphaZeroConfig
+    mod, cls = {'ttt': ('alphazero.games.tictactoe', 'TicTacToe'), 'c4': ('alphazero.games.connectfour', 'ConnectFour')}[name]
+    return AlphaZeroConfig(conf={'game': {'module': mod, 'name': cls}})
+
+
+def _golden_game(cfg, g):
+    game = cfg.Game()
+    for a, n in zip(g['history'], g['visits']):
+        game.take_action(a, np.array(n, dtype=np.uint32))
+    return game
+
+
+def _db_rows(path):
+    import sqlite3
+    con = sqlite3.connect(path)
+    games = [[r[0], r[1], r[2], bytes(r[3]).hex()] for r in
+             con.execute('SELECT id, model_version, history, search_statistics FROM selfplay_games ORDER BY id')]
+    states = [list(r) for r in con.execute('SELECT id, game_id, move_index FROM game_states ORDER BY id')]
+    con.close()
+    return games, states
+
+
+@pytest.mark.parametrize('which', [0, 1])
+def test_replay_database_matches_the_reference_rows_and_samples(tmp_path, which):
+    # host.json holds what the reference's SelfPlayDatabase.write_game stored for these games and what
+    # its ReplayBufferDataset.__getitem__ returned (alphazero/replay_buffer.py:28-47, 115-158)
+    from alphazero_amd.replay_buffer import ReplayBufferDataset, SelfPlayDatabase
+    case = load_json('host.json')['replay'][which]
+    cfg = _host_cfg(case['game'])
+    path = str(tmp_path / 'replay.sqlite')
+    ds = ReplayBufferDataset(cfg, path)
+    for g in case['games']:
+        ds.add_game(_golden_game(cfg, g), g['model_version'])
+    games, states = _db_rows(path)
+    assert games == case['selfplay_games'] and states == case['game_states']
+    assert (ds.db.num_games(), ds.db.num_states(), ds.db.num_distinct_games()) == \
+        (case['num_games'], case['num_states'], case['num_distinct_games'])
+
+    def check_items(d):
+        assert len(d) == len(case['items'])
+        for i, want in enumerate(case['items']):
+            if want is None:        # Connect Four, every tenth state: the reference needs an external solver binary
+                continue
+            got = d[i]
+            for k, dt in (('x', np.float32), ('z', np.float32), ('p', np.float32), ('move_scores', np.float32)):
+                assert np.array_equal(np.asarray(got[k], np.float32).reshape(-1), unhex(want[k], '<f4')), (i, k)
+            assert [int(b) for b in got['p_valid']] == want['p_valid']
+            for k in ('game_index', 'move_index', 'model_version', 'solved', 'v*'):
+                assert got[k] == want[k], (i, k)
+    check_items(ds)
+    check_items(ReplayBufferDataset(cfg, path))              # an existing database is read back on open
+    db = SelfPlayDatabase.connect(path)
+    g, version = db.read_game(1, cfg.Game())
+    assert g.history == case['games'][1]['history'] and version == case['games'][1]['model_version']
+    assert db.read_state(3) == (case['game_states'][3][1] - 1, case['game_states'][3][2])
+    with pytest.raises(ValueError):
+        db.read_state(10 ** 6)
+
+
+def test_record_sink_writes_reference_rows(tmp_path):
+    import ctypes as C
+    from alphazero_amd._lib import GameRecord
+    from alphazero_amd.replay_buffer import RecordSink
+    case = load_json('host.json')['replay'][1]
+    raw = np.zeros((len(case['games']), C.sizeof(GameRecord)), np.uint8)
+    for i, g in enumerate(case['games']):
+        r = GameRecord()
+        r.uid, r.num_moves, r.winner, r.model_version = i, len(g['history']), 0, g['model_version']
+        for m, (a, n) in enumerate(zip(g['history'], g['visits'])):
+            r.history[m], r.num_edges[m] = a, len(n)
+            for j, c in enumerate(n):
+                r.visits[m][j] = c
+        raw[i] = np.frombuffer(bytes(r), np.uint8)
+    path = str(tmp_path / 'sink.sqlite')
+    sink = RecordSink(path)
+    sink.put(raw[:1])
+    sink.put(raw[1:])
+    sink.close()
+    assert sink.games_written == len(case['games'])
+    games, states = _db_rows(path)
+    assert games == case['selfplay_games'] and states == case['game_states']
+
+
+def test_tictactoe_solver_matches_reference():
+    from alphazero_amd.games.tictactoe import TicTacToe
+    for c in load_json('host.json')['ttt_solve']:
+        scores, v = TicTacToe(history=c['history']).solve()
+        assert [int(s) for s in scores] == c['scores'] and v == c['v'], c['history']
+
+
+def test_solver_players_always_draw_tictactoe():
+    # alphazero/eval.py:79-132 with both sides on the solver: perfect play is a draw
+    from alphazero_amd.eval import SolverPlayer, match, play
+    from alphazero_amd.games.tictactoe import TicTacToe
+    np.random.seed(1)
+    assert match(TicTacToe, [SolverPlayer(), SolverPlayer()], 6) == (0, 6, 0)
+    g = TicTacToe(history=[4, 1])                      # a lost position for the side that took an edge
+    assert play(g, [SolverPlayer(), SolverPlayer()]) and g.winner == 0
