@@ -147,10 +147,18 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    # AZ_BENCH_REHEARSE=1: every rank on GPU 0 with the gloo backend -- a rehearsal of the N > 1 code
+    # path on a one-GPU box (RCCL refuses two ranks on one device); never a measurement
+    rehearse = os.environ.get('AZ_BENCH_REHEARSE') == '1'
+    if rehearse:
+        local = 0
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if rehearse:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
     else:
         torch.cuda.set_device(0)
     dev = torch.device('cuda', local if world > 1 else 0)
@@ -223,7 +231,7 @@ def main():
             # travel to the replay rank as raw records (replaces replay_buffer.py:28-47)
             raw = eng.drain_finished_bytes()
             if world > 1:
-                gather_record_bytes(raw, dst=0, device=dev)
+                gather_record_bytes(raw, dst=0, device='cpu' if rehearse else dev)
 
     def sync_all():
         if world > 1:
@@ -267,6 +275,7 @@ def main():
 
     positions = world * G * args.steps
     out = {
+        **({'rehearsal': 'all ranks on one GPU over gloo: not a measurement'} if rehearse else {}),
         'metric': 'Connect4 self-play positions/s (800 sims/move)',
         'value': positions / elapsed,
         'unit': 'positions/s',
