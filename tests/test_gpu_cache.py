@@ -10,13 +10,14 @@ pytestmark = pytest.mark.gpu
 
 def _play(net_modules, log2_entries, G=512, S=48, moves=14, game='c4'):
     from alphazero_amd import engine as E
-    from alphazero_amd.net import FusedC4Net
+    from alphazero_amd.net import C4Net128, FusedC4Net
     dev = torch.device('cuda', 0)
     eng = E.SelfPlayEngine(E._lib.GAME_C4, G, S, exploration_depth=4, reuse_search_tree=True,
                            alpha=0.3, epsilon=0.25, seed=11, device=0)
     if log2_entries:
         eng.enable_eval_cache(log2_entries)
-    fused = [FusedC4Net.from_module(m.to(dev), dev) for m in net_modules]
+    fused = [FusedC4Net.from_module(m.to(dev), dev) if m.block_channels <= 32 else C4Net128(m.to(dev), dev, max_leaves=G)
+             for m in net_modules]
     out = []
     kinds = set()
     for mv in range(moves):
@@ -66,6 +67,19 @@ def test_cache_on_off_identical():
         assert hits > 0
         if log2 == 20:
             assert 4 in kinds1 and hits > st1['leaf_evals'] // 10
+
+
+def test_cache_on_off_identical_128_channel_network():
+    torch.manual_seed(4)
+    from alphazero_amd.models import AlphaZeroC4
+    nets = [AlphaZeroC4(2, 128).eval()]
+    ref, st0, _, rec0, _ = _play(nets, 0, G=192, S=24, moves=8)
+    got, st1, hits, rec1, kinds = _play(nets, 16, G=192, S=24, moves=8)
+    for (a0, v0, w0), (a1, v1, w1) in zip(ref, got):
+        np.testing.assert_array_equal(a0, a1)
+        np.testing.assert_array_equal(v0, v1)
+    assert st0 == st1 and hits > 0 and 4 in kinds
+    np.testing.assert_array_equal(rec0, rec1)
 
 
 def _hash_evaluator(G, A, dev):
