@@ -262,3 +262,77 @@ class C4Net128:
         check(self.lib.az_c4net128_bf16_forward(ptr(self.blob), self.num_blocks, ptr(leaf_bb), ptr(leaf_info), n,
                                                 ptr(self.workspace), ptr(self._p), ptr(self._v), st))
         return self._p, self._v
+
+
+TTT_WIDTHS = (4, 8, 16)      # trunk channels of the tic-tac-toe kernel (csrc/az_net_ttt.hip)
+
+
+def pack_ttt_blob_f32(model):
+    """AlphaZero module with shape_in (2,3,3), shape_out (9,) -> float32 tensor in the layout of
+    csrc/az_net_ttt.hip (BN folded in float64, then rounded once to float32)."""
+    C_ = model.block_channels
+    if tuple(model.shape_in) != (2, 3, 3) or tuple(model.shape_out) != (9,) or C_ not in TTT_WIDTHS:
+        raise ValueError('tic-tac-toe kernel: shape_in (2,3,3), shape_out (9,), 4, 8 or 16 trunk channels')
+    dev = model._cbr[0].weight.device
+    z = lambda *shape: torch.zeros(*shape, dtype=torch.float64, device=dev)
+
+    def taps(w):                                   # [co][ci][3][3] -> [ci][co][12]
+        out = z(w.shape[1], w.shape[0], 12)
+        out[:, :, :9] = w.permute(1, 0, 2, 3).reshape(w.shape[1], w.shape[0], 9)
+        return out
+
+    with torch.no_grad():
+        w, b0 = _fold_bn(model._cbr[0].weight, model._cbr[1])
+        stem = taps(w)
+        c1, c2, b1, b2 = z(C_, C_, 12), z(C_, C_, 12), z(C_), z(C_)
+        if len(model._tower):
+            blk = model._tower[0]
+            w, b1 = _fold_bn(blk._c1.weight, blk._bn1)
+            c1 = taps(w)
+            w, b2 = _fold_bn(blk._c2.weight, blk._bn2)
+            c2 = taps(w)
+        ph, vh = model._policy_head, model._value_head
+        wpol, bpol = _fold_bn(ph._cbr[0].weight, ph._cbr[1], ph._cbr[0].bias)
+        wval, bval = _fold_bn(vh._cbr[0].weight, vh._cbr[1])
+        hw = torch.cat([wpol[:, :, 0, 0], wval[:, :, 0, 0]])                      # [3][C]
+        hb = torch.cat([bpol, bval, z(1)])
+        pfc = z(9, 20)
+        pfc[:, :18] = ph._fc.weight.double()
+        pb = torch.cat([ph._fc.bias.double(), z(3)])
+        v1 = z(256, 12)
+        v1[:, :9] = vh._fc[0].weight.double()
+        parts = [stem, c1, c2, torch.stack([b0, b1, b2]), hw, hb, pfc, pb, v1, vh._fc[0].bias.double(),
+                 vh._fc[2].weight.double(), torch.cat([vh._fc[2].bias.double().reshape(1), z(3)])]
+        blob = torch.cat([t.reshape(-1) for t in parts]).float().contiguous()
+    assert blob.numel() == _lib.load().az_tttnet_f32_blob_floats(C_), blob.numel()
+    return blob
+
+
+class TTTNetF32:
+    """Tic-tac-toe evaluator: net(leaf_bb, leaf_info) -> (p float32[n,9], v float32[n]); with
+    leaf_info only the rows that need the network are evaluated and written."""
+
+    def __init__(self, model, device=None):
+        self.lib = _lib.load()
+        self.device = torch.device(device if device is not None else next(model.parameters()).device)
+        self.num_blocks, self.channels = model.num_blocks, model.block_channels
+        self.blob = pack_ttt_blob_f32(model).to(self.device)
+        self._p = self._v = None
+
+    @classmethod
+    def supports(cls, model):
+        return (getattr(model, 'shape_in', None) == (2, 3, 3) and getattr(model, 'shape_out', None) == (9,)
+                and getattr(model, 'block_channels', None) in TTT_WIDTHS)
+
+    def load_module(self, model):
+        self.blob.copy_(pack_ttt_blob_f32(model))
+
+    def __call__(self, leaf_bb, leaf_info=None):
+        n = leaf_bb.shape[0]
+        if self._p is None or self._p.shape[0] != n:
+            self._p = torch.zeros(n, 9, dtype=torch.float32, device=self.device)
+            self._v = torch.zeros(n, dtype=torch.float32, device=self.device)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(self.lib.az_tttnet_f32_forward(ptr(self.blob), self.channels, self.num_blocks, ptr(leaf_bb),
+                                             ptr(leaf_info), n, ptr(self._p), ptr(self._v), st))
+        return self._p, self._v

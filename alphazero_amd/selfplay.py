@@ -47,14 +47,19 @@ class SelfPlayWorker:
         self._evaluator = evaluator           # callable(leaf_bb, leaf_info) -> (p, v); None = built-in
         self._fused = None
         if evaluator is None:
-            # Connect Four nets run in hand-written HIP kernels: up to 32 trunk channels in the
-            # one-launch fused kernel, 128 channels in the stem / tower / heads kernels
-            from .models import AlphaZeroC4
-            from .net import CMAX, C4Net128, FusedC4Net
+            # the shipped nets run in hand-written HIP kernels: Connect Four with up to 32 trunk
+            # channels in the one-launch fused kernel and with 128 channels in the stem / tower / heads
+            # kernels, tic-tac-toe (4, 8 or 16 channels) in its own fp32 kernel; anything else is
+            # evaluated by calling the torch module on the rendered leaves
+            from .models import AlphaZero, AlphaZeroC4
+            from .net import CMAX, C4Net128, FusedC4Net, TTTNetF32
             if isinstance(self._model, AlphaZeroC4) and self._model.block_channels <= CMAX:
                 self._fused = FusedC4Net.from_module(self._model, self._device)
             elif isinstance(self._model, AlphaZeroC4) and self._model.block_channels == 128:
                 self._fused = C4Net128(self._model, self._device, max_leaves=self.num_games)
+            elif (type(self._model) is AlphaZero and self._game_cls.AZ_GAME_ID == _engine._lib.GAME_TTT
+                  and TTTNetF32.supports(self._model)):
+                self._fused = TTTNetF32(self._model, self._device)
         if eval_cache_log2:
             # leaves whose position was already evaluated under the current model version are answered
             # by the engine; sound only for evaluators that are pure, batch-independent functions of

@@ -235,6 +235,18 @@ int  az_c4net128_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uin
                               const int32_t* leaf_info, int32_t n, void* workspace, float* p, float* v,
                               void* stream);
 
+/* Tic-tac-toe network (alphazero/models.py:70-87 with shape_in [2,3,3], shape_out [9], as in
+ * alphazero/config/tictactoe.yaml:4-11) entirely in fp32, one launch: stem, shared residual block x
+ * num_blocks, policy head with soft-max over the empty squares (mcts.py:101-106), value head.
+ * channels = 4, 8 or 16 trunk channels.  blob = DEVICE float buffer of
+ * az_tttnet_f32_blob_floats(channels) floats (alphazero_amd/net.py pack_ttt_blob_f32; -1 for an
+ * unsupported width).  leaf_bb as written by the engine (bit = square); leaf_info may be NULL (every
+ * row is evaluated), else only rows of kind EVAL / ROOT are evaluated and written.
+ * p float[n][9], v float[n].                                                                      */
+int  az_tttnet_f32_blob_floats(int32_t channels);
+int  az_tttnet_f32_forward(const float* blob, int32_t channels, int32_t num_blocks, const uint64_t* leaf_bb,
+                           const int32_t* leaf_info, int32_t n, float* p, float* v, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -252,3 +252,83 @@ def test_hip_networks_reproduce_the_reference_outputs():
                 assert abs(v[i] - v_ref) <= atol + rtol * abs(v_ref)
                 checked += 1
     assert checked > 2000
+
+
+def _random_ttt_positions(n, seed):
+    rng = np.random.RandomState(seed)
+    bb = np.zeros((n, 2), np.int64)
+    for i in range(n):
+        h = []
+        depth = rng.randint(0, 9)
+        while len(h) < depth and not orc.terminal(orc.TTT, h):
+            h.append(int(rng.choice(orc.valid_actions(orc.TTT, h))))
+        if orc.terminal(orc.TTT, h):
+            h = h[:-1]
+        nx = pv = 0
+        for a in h:
+            nx, pv = pv, nx | (1 << a)
+        bb[i] = (nx, pv)
+    return bb
+
+
+@pytest.mark.parametrize('blocks,ch,n', [(3, 16, 4099), (1, 4, 37), (2, 8, 1000), (0, 16, 5), (3, 16, 1)])
+def test_tictactoe_fp32_forward_matches_torch_fp32(blocks, ch, n):
+    """az_tttnet_f32_forward against the fp32 torch statement of alphazero/models.py:70-87 on the rendered
+    positions, soft-max over the empty squares as alphazero/mcts.py:101-106: rtol 1e-5 / atol 1e-6."""
+    from alphazero_amd import engine as E
+    from alphazero_amd.models import AlphaZero
+    from alphazero_amd.net import TTTNetF32
+    torch.manual_seed(blocks * 100 + ch)
+    model = AlphaZero((2, 3, 3), (9,), blocks, ch).eval()
+    _randomize_bn(model, 5)
+    model.cuda()
+    bb = torch.from_numpy(_random_ttt_positions(n, n)).cuda()
+    x, valid = E.render(0, bb)
+    with torch.no_grad():
+        logits, v_ref = model(x, valid.bool())
+        p_ref = torch.softmax(logits.masked_fill(~valid.bool(), float('-inf')), dim=1)
+    net = TTTNetF32(model, 'cuda')
+    p, v = net(bb, None)
+    assert torch.allclose(p, p_ref, rtol=1e-5, atol=1e-6), float((p - p_ref).abs().max())
+    assert torch.allclose(v, v_ref.view(-1), rtol=1e-5, atol=1e-6), float((v - v_ref.view(-1)).abs().max())
+    assert torch.all(p[~valid.bool()] == 0)
+    # with leaf_info only EVAL / ROOT rows are written; the others keep what was there
+    kinds = torch.from_numpy(np.random.RandomState(1).randint(0, 5, size=n).astype(np.int32)).cuda()
+    info = kinds | (valid.to(torch.int32) << torch.arange(16, 25, device='cuda', dtype=torch.int32)[None, :]).sum(1).to(torch.int32)
+    net._p.fill_(-7.0)
+    net._v.fill_(-7.0)
+    p2, v2 = net(bb, info)
+    need = (kinds == 1) | (kinds == 3)
+    assert torch.allclose(p2[need], p_ref[need], rtol=1e-5, atol=1e-6) and torch.all(p2[~need] == -7.0)
+    assert torch.allclose(v2[need], v_ref.view(-1)[need], rtol=1e-5, atol=1e-6) and torch.all(v2[~need] == -7.0)
+
+
+def test_tictactoe_kernel_reproduces_the_reference_outputs():
+    """The tic-tac-toe kernel against the (p, v) the REFERENCE's AlphaZero net returned while the golden
+    tic-tac-toe game was played (tests/golden/selfplay_net.json): within 1e-5 relative."""
+    from helpers import eval_table, golden_net_model, golden_net_positions, load_json
+    from alphazero_amd import engine as E
+    from alphazero_amd.models import AlphaZero
+    from alphazero_amd.net import TTTNetF32
+    checked = 0
+    for case in load_json('selfplay_net.json'):
+        if case['game'] != 'ttt':
+            continue
+        model = golden_net_model(case, AlphaZero)
+        keys, x = golden_net_positions(case, (2, 3, 3))
+        tab = eval_table(case)
+        w = (1 << np.arange(9, dtype=np.int64)).reshape(3, 3)
+        bb_np = np.stack([(x[:, pl].astype(np.int64) * w[None]).sum(axis=(1, 2)) for pl in (0, 1)], axis=1)
+        bb = torch.from_numpy(bb_np).cuda()
+        xr, valid = E.render(0, bb)
+        assert np.array_equal(xr.cpu().numpy(), x)
+        valid = valid.cpu().numpy().astype(bool)
+        p, v = TTTNetF32(model, 'cuda')(bb, None)
+        p, v = p.cpu().numpy(), v.cpu().numpy()
+        for i, k in enumerate(keys):
+            p_ref, v_ref = tab[k]
+            assert np.allclose(p[i][valid[i]], p_ref, rtol=1e-5, atol=1e-6), i
+            assert np.all(p[i][~valid[i]] == 0)
+            assert abs(v[i] - v_ref) <= 1e-6 + 1e-5 * abs(v_ref)
+            checked += 1
+    assert checked > 50

@@ -257,3 +257,25 @@ def test_match_play_against_the_solver_and_solver_metrics(tmp_path):
                 'data/distinct_games', 'data/total_states'):
         assert tag in w.tags and np.isfinite(w.tags[tag]), tag
     assert w.tags['data/total_states'] == len(ds) and w.tags['eval/policy_target_KL'] >= 0
+
+
+def test_tictactoe_net_runs_in_the_hip_kernel():
+    """The shipped tic-tac-toe architecture (alphazero/config/tictactoe.yaml:4-11: 3 blocks x 16 channels)
+    is evaluated by az_tttnet_f32_forward inside the worker, not by the torch module."""
+    from alphazero_amd.net import TTTNetF32
+    from alphazero_amd.selfplay import SelfPlayWorker
+    cfg = _config({'module': 'alphazero.games.tictactoe', 'name': 'TicTacToe'},
+                  {'module': 'alphazero.models', 'name': 'AlphaZero',
+                   'kwargs': {'shape_in': [2, 3, 3], 'shape_out': [9], 'num_blocks': 3, 'block_channels': 16}},
+                  S=32, depth=3)
+    torch.manual_seed(1)
+    state = cfg.Model().state_dict()
+    ds = _Dataset()
+    worker = SelfPlayWorker(cfg, _Server(5, state), ds, 'cuda:0', num_games=256, seed=9)
+    assert isinstance(worker._fused, TTTNetF32)
+    calls = []
+    worker._model.forward = lambda *a, **k: calls.append(1)        # the torch module must not be called
+    assert worker.play_game() == 5
+    assert not calls
+    _check_games(ds, orc.TTT, 32, True)
+    assert all(v == 5 for _, v in ds.games)
