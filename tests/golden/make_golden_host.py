@@ -8,6 +8,8 @@ Usage:  PYTHONPATH=/root/reference PYTHONDONTWRITEBYTECODE=1 python3 tests/golde
     few finished games (taken from selfplay_exact.json), blobs as hex
   * alphazero.replay_buffer.ReplayBufferDataset.__getitem__ -> every sample dict of that database
   * alphazero.games.tictactoe.TicTacToe.solve             -> (scores, v) for a set of positions
+  * alphazero.training.TrainingWorker.process_batch       -> four SGD steps on the CPU: every logged
+    scalar and the weights before and after
 Only data is written (host.json); no reference source is copied.
 """
 import json
@@ -90,13 +92,68 @@ def solve_cases():
     return out
 
 
+TRAIN_CONF = {
+    'game': {'module': 'alphazero.games.tictactoe', 'name': 'TicTacToe'},
+    'model': {'module': 'alphazero.models', 'name': 'AlphaZero',
+              'kwargs': {'shape_in': [2, 3, 3], 'shape_out': [9], 'num_blocks': 2, 'block_channels': 4}},
+    'loss': {'module': 'alphazero.loss', 'name': 'AlphaZeroLoss'},
+    'training': {'num_steps': 4, 'batch_size': 8, 'lr': 0.05, 'momentum': 0.9, 'weight_decay': 1.0e-4,
+                 'lr_schedule_gamma': 0.1, 'lr_schedule': [2]},
+}
+
+
+def training_case(cases):
+    """alphazero.training.TrainingWorker.process_batch x 4 on the CPU: the four tic-tac-toe games in a
+    SQLite replay buffer, seeded model init and sampler; every logged scalar and the final weights."""
+    import torch
+    import yaml
+    from alphazero.config import AlphaZeroConfig
+    from alphazero.training import TrainingWorker
+    tmp = tempfile.mkdtemp()
+    with open(os.path.join(tmp, 'config.yaml'), 'w') as f:
+        yaml.safe_dump(TRAIN_CONF, f)
+    cfg = AlphaZeroConfig(os.path.join(tmp, 'config.yaml'))
+    ds = ReplayBufferDataset(cfg, os.path.join(tmp, 'replay.sqlite'))
+    for case in cases:
+        g = TicTacToe()
+        for mv in case['moves']:
+            g.take_action(mv['action'], np.array(mv['N'], dtype=np.uint32))
+        ds.add_game(g, 1)
+
+    class Server:
+        versions = []
+
+        def update(self, model, version):
+            self.versions.append(int(version))
+
+    class Writer:
+        def __init__(self):
+            self.rows = []
+
+        def add_scalar(self, tag, value, step):
+            self.rows.append([tag, float(value), int(step)])
+
+    torch.manual_seed(11)
+    np.random.seed(12)
+    server, writer = Server(), Writer()
+    tw = TrainingWorker(cfg, server, ds, writer, 'cpu', 0)
+    init = {k: fhex(v.detach().float().numpy()) for k, v in tw._model.state_dict().items() if v.dtype.is_floating_point}
+    returns = [int(tw.process_batch()) for _ in range(4)]
+    final = {k: fhex(v.detach().float().numpy()) for k, v in tw._model.state_dict().items() if v.dtype.is_floating_point}
+    return {'conf': TRAIN_CONF, 'model_seed': 11, 'sampler_seed': 12, 'returns': returns, 'versions': server.versions,
+            'scalars': writer.rows, 'init': init, 'final': final,
+            'games': [{'history': list(c['history']), 'visits': [list(map(int, mv['N'])) for mv in c['moves']]}
+                      for c in cases]}
+
+
 def main():
     warnings.simplefilter('ignore')
     cases = json.load(open(os.path.join(HERE, 'selfplay_exact.json')))
     ttt = [c for c in cases if c['game'] == 'ttt'][:4]
     c4 = [c for c in cases if c['game'] == 'c4' and c['S'] <= 200][:3] + [c for c in cases if c['game'] == 'c4' and c['S'] == 800][:1]
     out = {'replay': [replay_case('ttt', ttt, [0, 3, 3, 7]), replay_case('c4', c4, [1, 2, 2, 40000])],
-           'ttt_solve': solve_cases()}
+           'ttt_solve': solve_cases(),
+           'training': training_case(ttt)}
     with open(os.path.join(HERE, 'host.json'), 'w') as f:
         json.dump(out, f, separators=(',', ':'))
     print('written', os.path.join(HERE, 'host.json'))

@@ -295,3 +295,47 @@ def test_solver_players_always_draw_tictactoe():
     assert match(TicTacToe, [SolverPlayer(), SolverPlayer()], 6) == (0, 6, 0)
     g = TicTacToe(history=[4, 1])                      # a lost position for the side that took an edge
     assert play(g, [SolverPlayer(), SolverPlayer()]) and g.winner == 0
+
+
+def test_training_steps_match_the_reference_on_cpu():
+    # host.json 'training': four process_batch() calls of the reference's TrainingWorker
+    # (alphazero/training.py:42-125) on the CPU with seeded init and sampler; same seeds here
+    from alphazero_amd.config import AlphaZeroConfig
+    from alphazero_amd.replay_buffer import ReplayBufferDataset
+    from alphazero_amd.training import TrainingWorker
+    t = load_json('host.json')['training']
+    cfg = AlphaZeroConfig(conf=t['conf'])
+    ds = ReplayBufferDataset(cfg)
+    for g in t['games']:
+        ds.add_game(_golden_game(cfg, g), 1)
+
+    class Server:
+        versions = []
+
+        def update(self, model, version):
+            self.versions.append(int(version))
+
+    class Writer:
+        rows = []
+
+        def add_scalar(self, tag, value, step):
+            self.rows.append([tag, float(value), int(step)])
+
+    torch.manual_seed(t['model_seed'])
+    np.random.seed(t['sampler_seed'])
+    server, writer = Server(), Writer()
+    tw = TrainingWorker(cfg, server, ds, writer, 'cpu', 0)
+    state = tw.model.state_dict()
+    for k, h in t['init'].items():
+        assert np.array_equal(state[k].detach().numpy().reshape(-1), unhex(h, '<f4')), k     # same initialisation
+    assert [tw.process_batch() for _ in range(4)] == t['returns'] and server.versions == t['versions']
+    assert [(r[0], r[2]) for r in writer.rows] == [(r[0], r[2]) for r in t['scalars']]
+    for got, want in zip(writer.rows, t['scalars']):
+        assert abs(got[1] - want[1]) <= 1e-6 * max(1.0, abs(want[1])), (got, want)
+    state = tw.model.state_dict()
+    exact = 0
+    for k, h in t['final'].items():
+        a, b = state[k].detach().numpy().reshape(-1), unhex(h, '<f4')
+        assert np.allclose(a, b, rtol=1e-6, atol=1e-7), k
+        exact += int(np.array_equal(a, b))
+    assert exact == len(t['final'])         # in fact bit-identical on this torch build
