@@ -9,6 +9,7 @@ ROOT=$(pwd)
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 BENCH="bench.py --no-cpu-baseline --steps 3 --warmup 1"
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_net" -- python3 $BENCH > "$OUT/bench_net.log" 2>&1
+timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_net_cache" -- python3 $BENCH --eval-cache-log2 24 > "$OUT/bench_net_cache.log" 2>&1
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_uniform" -- python3 $BENCH --model uniform > "$OUT/bench_uniform.log" 2>&1
 timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/net128" -- python3 tools/net128_bench.py 16384 > "$OUT/net128.log" 2>&1
 timeout -s KILL 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 $BENCH --preroll 8 > "$OUT/pmc_fetch.log" 2>&1

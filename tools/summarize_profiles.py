@@ -12,7 +12,7 @@ import sys
 out = sys.argv[1]
 summ = os.path.join(out, 'summary')
 os.makedirs(summ, exist_ok=True)
-for name in ('bench_net', 'bench_uniform', 'net128'):
+for name in ('bench_net', 'bench_net_cache', 'bench_uniform', 'net128'):
     for f in glob.glob(os.path.join(out, name, '*', '*kernel_stats.csv')):
         shutil.copy(f, os.path.join(summ, f'{name}_kernel_stats.csv'))
     log = os.path.join(out, name + '.log')
