@@ -276,7 +276,7 @@ def main():
     positions = world * G * args.steps
     out = {
         **({'rehearsal': 'all ranks on one GPU over gloo: not a measurement'} if rehearse else {}),
-        'metric': 'Connect4 self-play positions/s (800 sims/move)',
+        'metric': f'Connect4 self-play positions/s ({S} sims/move)',
         'value': positions / elapsed,
         'unit': 'positions/s',
         'sims_per_s': world * sims / elapsed,
