@@ -78,6 +78,8 @@ def replay_case(game_name, cases, versions):
 def solve_cases():
     rng = np.random.RandomState(5)
     hists = [[]] + [[a] for a in range(9)] + [[a, b] for a in range(9) for b in range(9) if a != b]
+    kat = [0, 2, 8, 4, 6, 7, 3]              # the line the reference's own solver test walks (test_games.py:70)
+    hists += [kat[:i] for i in range(3, len(kat))]
     for _ in range(120):
         g = TicTacToe()
         n = rng.randint(3, 9)

@@ -337,3 +337,34 @@ def test_pool_exhaustion_is_reported():
     eng.run_sims_uniform(64)
     assert eng.stats()['errors'] == 2
     eng.close()
+
+
+def test_search_statistics_survive_the_sqlite_replay_buffer(tmp_path):
+    """alphazero/test/test_mcts.py:14-66 on this package: 64 simulations per fresh root with the
+    UniformModel, a forced tic-tac-toe line, the SQLite-backed dataset returns exactly the searched
+    distribution and the alternating outcome."""
+    import os
+    from alphazero_amd.config import AlphaZeroConfig
+    from alphazero_amd.mcts import MCTreeNode, run_mcts
+    from alphazero_amd.replay_buffer import ReplayBufferDataset
+    cfg = AlphaZeroConfig(conf={'game': {'module': 'alphazero.games.tictactoe', 'name': 'TicTacToe'},
+                                'model': {'module': 'alphazero.models', 'name': 'UniformModel'}})
+    model, game = cfg.Model(), cfg.Game()
+    ds = ReplayBufferDataset(cfg, os.path.join(str(tmp_path), 'test.sqlite'))
+    line = [0, 2, 8, 4, 6, 7, 3]
+    stats = np.zeros((len(line), game.NUM_ACTIONS))
+    np.random.seed(0)
+    for i, action in enumerate(line):
+        root = MCTreeNode()
+        run_mcts(game, root, model, 64)
+        assert np.sum(root.num_visits) == 64
+        stats[i, game.valid_actions] = root.num_visits
+        game.take_action(action, search_statistics=root.num_visits)
+    ds.add_game(game, 0)
+    assert len(ds) == len(line)
+    for d in (ds, ReplayBufferDataset(cfg, os.path.join(str(tmp_path), 'test.sqlite'))):
+        for i in range(len(d)):
+            ex = d[i]
+            assert np.sum(ex['p_valid']) == 9 - i
+            assert np.all(ex['p'] == stats[i] / np.sum(stats[i]))
+            assert ex['z'] == (1 if i % 2 == 0 else -1)

@@ -339,3 +339,16 @@ def test_training_steps_match_the_reference_on_cpu():
         assert np.allclose(a, b, rtol=1e-6, atol=1e-7), k
         exact += int(np.array_equal(a, b))
     assert exact == len(t['final'])         # in fact bit-identical on this torch build
+
+
+def test_tictactoe_solver_known_line():
+    # the positions of alphazero/test/test_games.py:69-92, answers as the reference's solver gave them
+    from alphazero_amd.games.tictactoe import TicTacToe
+    line = [0, 2, 8, 4, 6, 7, 3]
+    table = {tuple(c['history']): c for c in load_json('host.json')['ttt_solve']}
+    for i in range(len(line)):
+        game = TicTacToe(history=line[:i])
+        want = table[tuple(line[:i])]
+        scores, v = game.solve()
+        assert len(game.valid_actions) == len(scores) and scores == want['scores'] and v == want['v']
+    assert table[(0, 2)]['scores'] == [-1, 2, 0, 0, 2, 0, 2] and table[(0, 2, 8, 4, 6, 7)]['scores'] == [0, 2, -1]
