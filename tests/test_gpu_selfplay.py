@@ -368,3 +368,49 @@ def test_search_statistics_survive_the_sqlite_replay_buffer(tmp_path):
             assert np.sum(ex['p_valid']) == 9 - i
             assert np.all(ex['p'] == stats[i] / np.sum(stats[i]))
             assert ex['z'] == (1 if i % 2 == 0 else -1)
+
+
+def test_golden_net_games_with_the_hip_networks_in_the_loop():
+    """The reference's recorded games with real networks, replayed with the fp32 HIP kernels (not the
+    recorded outputs) evaluating the leaves: the kernels agree with the reference's torch fp32 to ~1e-7,
+    which on these games leaves every PUCT arg-max, hence every visit count and move, unchanged; W and P
+    agree within 1e-5."""
+    from helpers import golden_net_model
+    from alphazero_amd import engine as E
+    from alphazero_amd.models import AlphaZero, AlphaZeroC4
+    from alphazero_amd.net import FusedC4NetF32, TTTNetF32
+    ran = 0
+    for case in load_json('selfplay_net.json'):
+        g = GAME[case['game']]
+        A = NUM_A[g]
+        if g == 1:
+            net = FusedC4NetF32(golden_net_model(case, AlphaZeroC4), 'cuda')
+        else:
+            net = TTTNetF32(golden_net_model(case, AlphaZero), 'cuda')
+        eng = E.SelfPlayEngine(g, 1, case['S'], exploration_depth=case['exploration_depth'],
+                               reuse_search_tree=case['reuse'], alpha=case['alpha'], epsilon=case['epsilon'],
+                               lut=load_lut())
+        for i, m in enumerate(case['moves']):
+            eta = torch.zeros(1, A, dtype=torch.float64, device='cuda')
+            e = unhex(m['eta'], '<f8')
+            eta[0, :len(e)] = torch.from_numpy(e)
+            bb, info = eng.begin_move()
+            p, _ = net(bb, None)
+            eng.apply_root(p, eta)
+            bb, info = eng.select()
+            for s in range(case['S']):
+                p, v = net(bb, None)
+                if s < case['S'] - 1:
+                    bb, info = eng.sim_step(p, v)
+                else:
+                    eng.expand_backup(p, v)
+            N, W, P = _root_edges(eng)
+            assert list(N) == m['N'], (case['net_kwargs'], i)
+            assert np.allclose(W, unhex(m['W'], '<f4'), rtol=1e-5, atol=1e-5)
+            assert np.allclose(P, unhex(m['P'], '<f4'), rtol=1e-5, atol=1e-6)
+            u = torch.from_numpy(unhex(m['u'], '<f8')).cuda() if 'u' in m else None
+            act, _, _, win = eng.choose_and_advance(u)
+            assert int(act[0]) == m['action'], i
+        eng.close()
+        ran += 1
+    assert ran >= 4
