@@ -504,9 +504,9 @@ __device__ __forceinline__ void select_leaf_g(const Dev& E, const uint4* pool, u
     uint32_t hint = ns_hint;
     double2 lt = make_double2(0.0, 0.0);
     if (active) lt = lut_fetch(E, hint);
+    uint4 e = make_uint4(0u, 0u, 0u, AZ_NO_NODE);
+    if (active && sub < AS) e = pool[(size_t)node * AS + sub];
     while (active) {
-        uint4 e = make_uint4(0u, 0u, 0u, AZ_NO_NODE);
-        if (sub < AS) e = pool[(size_t)node * AS + sub];
         const int n_edges = (int)G_::bcast(e.x, AS - 1);
         const uint32_t Ns = G_::bcast(e.y, AS - 1);
         if (Ns != hint) lt = lut_fetch(E, Ns);
@@ -519,7 +519,13 @@ __device__ __forceinline__ void select_leaf_g(const Dev& E, const uint4* pool, u
         const int slot = __ffs((int)hit) - 1;                          // np.argmax: first maximum
         const uint32_t child = G_::bcast(e.w, slot);
         hint = G_::bcast(e.x, slot) - 1u;
-        if (child != AZ_NO_NODE) lt = lut_fetch(E, hint);              // in flight with the child's line
+        // the child's line and its table entry are requested here, so that stepping the position and
+        // the win test below run while they travel
+        uint4 e_next = make_uint4(0u, 0u, 0u, AZ_NO_NODE);
+        if (child != AZ_NO_NODE) {
+            lt = lut_fetch(E, hint);
+            if (sub < AS) e_next = pool[(size_t)child * AS + sub];
+        }
         const int action = az_nth_set_bit(GM::legal(nx, pv), slot);    // mcts.py:126
         if (sub == 0) path[depth] = (node << 4) | (uint32_t)slot;
         depth += 1;
@@ -538,6 +544,7 @@ __device__ __forceinline__ void select_leaf_g(const Dev& E, const uint4* pool, u
         } else {
             node = child;
         }
+        e = e_next;
     }
 }
 
