@@ -6,6 +6,11 @@
     trainer    : DeviceReplayWindow.add_records -> TrainingWorker.process_batch (one SGD step)
     weights    : ModelServer.update on the trainer rank, ModelServer.sync (one broadcast) everywhere
 
+With data_parallel=True every rank trains instead: records are all-gathered, every rank keeps the same
+replay window and takes batch_size / world_size samples of its own per step, gradients are averaged
+with one all-reduce (distributed.allreduce_gradients) and the ranks' weights stay identical without
+any broadcast.
+
 Nothing here is on the measured hot path; it is the caller on either side of it."""
 import torch
 import torch.distributed as dist
@@ -17,7 +22,8 @@ from .training import TrainingWorker
 
 
 def synchronous_play_and_train(config, device, num_games=1024, num_steps=None, moves_per_step=1, logdir=None,
-                               summary_writer=None, seed=0, trainer_rank=0, window_states=64 * 1024, log=None):
+                               summary_writer=None, seed=0, trainer_rank=0, window_states=64 * 1024, log=None,
+                               data_parallel=False):
     """Runs until the model version reaches `num_steps` (default: config.training['num_steps']).
     Returns (model_server, selfplay_worker, training_worker or None)."""
     multi = dist.is_available() and dist.is_initialized()
@@ -27,14 +33,24 @@ def synchronous_play_and_train(config, device, num_games=1024, num_steps=None, m
     server = ModelServer(logdir if rank == trainer_rank else None)
     server.reset()
     worker = SelfPlayWorker(config, server, None, device, num_games=num_games, seed=seed, rank=rank, world_size=world)
+    data_parallel = bool(data_parallel and multi)      # then every rank's own store holds the same weights
     trainer = window = None
-    if rank == trainer_rank:
+    if rank == trainer_rank or data_parallel:
+        from .distributed import allreduce_gradients
         window = DeviceReplayWindow(type(config.Game()), window_states, device)
-        trainer = TrainingWorker(config, server, window, summary_writer, device)
+        if data_parallel:
+            share = config.training['batch_size'] // world
+            assert share * world == config.training['batch_size'], 'batch_size must divide by the number of ranks'
+            torch.manual_seed(seed)                        # identical initial weights on every rank ...
+            trainer = TrainingWorker(config, server, window, summary_writer if rank == trainer_rank else None, device,
+                                     grad_sync=allreduce_gradients, batch_size=share)
+            torch.manual_seed(seed + 1 + rank)             # ... and a different sample stream per rank
+        else:
+            trainer = TrainingWorker(config, server, window, summary_writer, device)
     version = 0
     while version < num_steps:
         # alphazero/selfplay.py:16-22: newest weights first (version 0 = UniformModel)
-        if multi:
+        if multi and not data_parallel:
             server.sync(worker._model, src=trainer_rank)
         worker.refresh_model()
         uniform = worker._version <= 0
@@ -43,13 +59,13 @@ def synchronous_play_and_train(config, device, num_games=1024, num_steps=None, m
         raw = worker.collect_finished_bytes()
         if multi:
             from .distributed import gather_record_bytes
-            raw = gather_record_bytes(raw, dst=trainer_rank, device=device)
-        if rank == trainer_rank:
+            raw = gather_record_bytes(raw, dst=None if data_parallel else trainer_rank, device=device)
+        if trainer is not None:
             window.add_records(raw)
             version = trainer.process_batch() or version          # 0 while the window is still too small
-            if log:
+            if log and rank == trainer_rank:
                 log(f'version {version}: {len(window)} states in the window, {window.num_games} games')
-        if multi:
+        if multi and not data_parallel:
             v = torch.tensor([version], dtype=torch.int64, device=device)
             dist.broadcast(v, trainer_rank)
             version = int(v.item())

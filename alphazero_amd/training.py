@@ -15,8 +15,13 @@ from .replay_buffer import ReplayBufferSampler
 
 
 class TrainingWorker:
-    def __init__(self, config, model_server, dataset, summary_writer, device, num_workers=0):
+    def __init__(self, config, model_server, dataset, summary_writer, device, num_workers=0, grad_sync=None,
+                 batch_size=None):
         self._config, self._model_server, self._dataset = config, model_server, dataset
+        # data-parallel use: grad_sync(model) runs between backward() and the optimizer step (e.g.
+        # distributed.allreduce_gradients) and batch_size is this rank's share of config's batch
+        self._grad_sync = grad_sync
+        self._batch_size = int(batch_size if batch_size is not None else config.training['batch_size'])
         self._writer, self._device, self._num_workers = summary_writer, device, num_workers
         self._model = config.Model().to(device)
         self._loss = config.Loss()
@@ -24,7 +29,7 @@ class TrainingWorker:
         self._optimizer = SGD(self._model.parameters(), lr=t['lr'], momentum=t['momentum'],
                               weight_decay=t['weight_decay'])
         self._lr_schedule = MultiStepLR(self._optimizer, t['lr_schedule'], gamma=t['lr_schedule_gamma'])
-        self._sampler = ReplayBufferSampler(dataset, batch_size=t['batch_size'], bufferlen=64 * 1024)
+        self._sampler = ReplayBufferSampler(dataset, batch_size=self._batch_size, bufferlen=64 * 1024)
         self._iter = 0
 
     @property
@@ -34,7 +39,7 @@ class TrainingWorker:
     def _batch(self):
         if hasattr(self._dataset, 'sample'):
             # DeviceReplayWindow: the window already lives on the GPU as tensors
-            b = self._dataset.sample(self._config.training['batch_size'])
+            b = self._dataset.sample(self._batch_size)
             return (b['x'].to(self._device), b['p'].to(self._device), b['z'].to(self._device),
                     b['p_valid'].to(self._device), None)
         items = [self._dataset[i] for i in next(self._sampler)]
@@ -67,7 +72,7 @@ class TrainingWorker:
                          masked_cross_entropy(p_hat, F.softmax(p_hat, dim=1), p_valid).mean(), it)
 
     def process_batch(self):
-        N, B = len(self._dataset), self._config.training['batch_size']
+        N, B = len(self._dataset), self._batch_size
         M = max(2 * self._num_workers, 1) * B
         if N < M:
             print(f'Skipping batch, too few examples in replay buffer ({N} < {M}).')
@@ -79,6 +84,8 @@ class TrainingWorker:
         self._optimizer.zero_grad()
         total = policy_loss + value_loss
         total.backward()
+        if self._grad_sync is not None:
+            self._grad_sync(self._model)
         self._optimizer.step()
         self._lr_schedule.step()
         it = self._iter

@@ -279,3 +279,44 @@ def test_tictactoe_net_runs_in_the_hip_kernel():
     assert not calls
     _check_games(ds, orc.TTT, 32, True)
     assert all(v == 5 for _, v in ds.games)
+
+
+def _dp_train_rank(rank, world, port, out_dir):
+    import os
+    import sys
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from alphazero_amd.train import synchronous_play_and_train
+    cfg = _config({'module': 'alphazero.games.connectfour', 'name': 'ConnectFour'},
+                  {'module': 'alphazero.games.connectfour', 'name': 'AlphaZeroC4',
+                   'kwargs': {'num_blocks': 1, 'channels_per_block': 8}}, S=12)
+    cfg._conf['loss'] = {'module': 'alphazero.loss', 'name': 'AlphaZeroLoss'}
+    cfg._conf['training'] = {'lr': 0.02, 'momentum': 0.9, 'weight_decay': 1e-4, 'lr_schedule': [100],
+                             'lr_schedule_gamma': 0.1, 'batch_size': 64, 'num_steps': 3}
+    server, worker, trainer = synchronous_play_and_train(cfg, torch.device('cuda', 0), num_games=128, num_steps=3,
+                                                         moves_per_step=2, seed=5, data_parallel=True)
+    assert trainer is not None and server._version == 3 and worker._version >= 2
+    flat = torch.cat([t.detach().reshape(-1).float() for t in trainer.model.state_dict().values()
+                      if t.dtype.is_floating_point])
+    both = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    assert torch.equal(both[0], both[1])                 # no broadcast, yet the ranks hold the same network
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(out_dir, f'dp{rank}'), 'w').write('ok')
+
+
+def test_data_parallel_play_and_train_two_ranks(tmp_path):
+    """train.synchronous_play_and_train(data_parallel=True) with two ranks (both on GPU 0, gloo standing in for
+    RCCL): records all-gathered, each rank trains on its own half batch, one gradient all-reduce per step,
+    weights identical at the end."""
+    import os
+    import torch.multiprocessing as mp
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_dp_train_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / 'dp0') and os.path.exists(tmp_path / 'dp1')
