@@ -27,10 +27,12 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/azhip.h"
 #include "az_games.h"
+#include "az_net_dev.h"
 
 #define WAVES_PER_BLOCK 4
 #define BLOCK_THREADS (64 * WAVES_PER_BLOCK)
@@ -96,7 +98,6 @@ struct az_engine {
 // wave helpers
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
-__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 __device__ __forceinline__ uint32_t uniu(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 
@@ -607,10 +608,12 @@ __device__ __forceinline__ void backup_g(uint4* pool, int depth, const uint32_t*
 //   DO_SELECT: start the next one; terminal leaves are backed up at once.
 // Everything the kernel needs from the slot, the saved path and (p, v) is requested up front in one
 // batch of loads, so the dependent chain is: slot -> edges to back up -> root -> one line per level.
-template <class GM, int GS, bool DO_EXPAND, bool DO_SELECT>
-__global__ void __launch_bounds__(BLOCK_THREADS)
-k_sim_step_p(Dev E, const float* p, const float* v, uint64_t* leaf_bb, int32_t* leaf_info) {
-    GROUP_PROLOGUE
+// `path` is the group's scratch for (node, slot) per level: a row of an LDS stack, or the slot's own
+// path array in global memory (PATH_IN_SLOT), in which case nothing has to be copied for the next launch.
+template <class GM, int GS, bool DO_EXPAND, bool DO_SELECT, bool PATH_IN_SLOT = false>
+__device__ __forceinline__ void sim_step_game(const Dev& E, const float* p, const float* v, uint64_t* leaf_bb,
+                                              int32_t* leaf_info, int g, int lane, int sub, Slot* s, uint4* pool,
+                                              uint32_t* path, int wave_id) {
     using G_ = Grp<GS>;
     constexpr int AS = GM::A + 1;
     const uint4* sh = reinterpret_cast<const uint4*>(s);
@@ -714,14 +717,14 @@ k_sim_step_p(Dev E, const float* p, const float* v, uint64_t* leaf_bb, int32_t* 
             }
             const unsigned long long hm = __ballot(hit && sub == 0);
             if (hm && lane == 0) {
-                unsigned long long* hc = E.cache_hits + (size_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+                unsigned long long* hc = E.cache_hits + wave_id;
                 *hc += (unsigned long long)__popcll(hm);
             }
         }
         if (kind == AZ_LEAF_TERMINAL) {
             backup_g<GM, GS>(pool, depth, path, vterm, sub);
             sims += 1;
-        } else if (kind == AZ_LEAF_EVAL || kind == AZ_LEAF_CACHED) {
+        } else if (!PATH_IN_SLOT && (kind == AZ_LEAF_EVAL || kind == AZ_LEAF_CACHED)) {
             for (int d = sub; d < depth; d += GS) s->path[d] = path[d];
         }
         if (sub == 0) {
@@ -740,6 +743,118 @@ k_sim_step_p(Dev E, const float* p, const float* v, uint64_t* leaf_bb, int32_t* 
         so[4] = make_uint4((uint32_t)st_sims, (uint32_t)(st_sims >> 32), (uint32_t)st_steps, (uint32_t)(st_steps >> 32));
         so[5] = make_uint4((uint32_t)st_evals, (uint32_t)(st_evals >> 32), c1.z, c1.w);
         if (DO_SELECT) s->leaf_nm = nm;
+    }
+}
+
+template <class GM, int GS, bool DO_EXPAND, bool DO_SELECT>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+k_sim_step_p(Dev E, const float* p, const float* v, uint64_t* leaf_bb, int32_t* leaf_info) {
+    GROUP_PROLOGUE
+    sim_step_game<GM, GS, DO_EXPAND, DO_SELECT>(E, p, v, leaf_bb, leaf_info, g, lane, sub, s, pool, path,
+                                                (int)blockIdx.x * WAVES_PER_BLOCK + (int)(threadIdx.x >> 6));
+}
+
+// ---------------------------------------------------------------------------
+// A whole move's simulations in ONE launch, Connect Four with the fused <= 32-channel network: a
+// workgroup owns `gpw` games from the first select to the last backup.  Per simulation its lanes run
+// the search step for their games (sim_step_game, 8 lanes per tree, path kept in the slot), a
+// workgroup barrier, the network for exactly those games' leaves (net_rounds: the task list is dealt
+// to the workgroup's four SIMD pairs as in k_c4net_bf16), another barrier.  A leaf is evaluated by
+// the workgroup that owns its game, so there is no grid-wide synchronisation, no kernel boundary
+// between search and network, and the tower weights are fetched once per move instead of once per
+// simulation.  Workgroups drift apart freely: what one waits for is only its own games.  The
+// network's outputs do not depend on which other leaves share a launch, so trees, visit counts and
+// records are bit-identical to the two-kernel path.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(NTHREADS, 2)
+k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, int32_t* leaf_info, float* p,
+                float* v, int num_sims, int gpw) {
+    constexpr int GS = 8;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t* bufX = lds;
+    uint8_t* bufY = lds + ACT_BYTES;
+    uint8_t* scr = lds + 2 * ACT_BYTES;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    {
+        uint4* z = reinterpret_cast<uint4*>(lds);
+        for (int i = tid; i < LDS_BYTES / 16; i += NTHREADS) z[i] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    if (tid < 100) reinterpret_cast<float*>(scr + S_BIAS)[tid] = reinterpret_cast<const float*>(blob + OFF_BIAS)[tid];
+    if (tid < 256) {
+        reinterpret_cast<float*>(scr + S_B1)[tid] = reinterpret_cast<const float*>(blob + OFF_B1)[tid];
+        reinterpret_cast<float*>(scr + S_W2)[tid] = reinterpret_cast<const float*>(blob + OFF_W2)[tid];
+    }
+    if (tid < 64) reinterpret_cast<float*>(scr + S_BP)[tid] = reinterpret_cast<const float*>(blob + OFF_BP)[tid];
+    Weights w1, w2;
+#pragma unroll
+    for (int s = 0; s < 18; ++s) {
+        w1.f[s] = frag_ptr(blob, OFF_WF, lane)[s * 64];
+        w2.f[s] = frag_ptr(blob, OFF_WF + 18 * 1024, lane)[s * 64];
+    }
+
+    // search lanes: thread t serves game g_base + t / 8 (gpw <= 64 games per workgroup).  Everything a
+    // search phase needs is re-derived from an opaque copy of the thread index at its start, so no
+    // pointer or index of the search has to stay in a register (or be spilled) across the network phase,
+    // which owns the register file.
+    const int wave_id = (int)blockIdx.x * (NTHREADS / 64) + wave;
+    int* tlist = reinterpret_cast<int*>(scr + S_TL);
+    int* wtot = reinterpret_cast<int*>(scr + S_WT);
+    auto search = [&](auto tag_expand, auto tag_select) {
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        const int gl = t / GS, sub = t & (GS - 1), ln = t & 63;
+        const int g = (int)blockIdx.x * gpw + gl;
+        if (gl < gpw && g < E.G) {
+            Slot* s = E.slots + g;
+            uint4* pool = E.pool + (size_t)g * E.cap * (GameC4::A + 1);
+            sim_step_game<GameC4, GS, decltype(tag_expand)::value, decltype(tag_select)::value, true>(
+                E, p, v, leaf_bb, leaf_info, g, ln, sub, s, pool, s->path, wave_id);
+        }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+
+    search(F_{}, T_{});
+    for (int sim = 0; sim < num_sims; ++sim) {
+        // the planes of the head phase and the task list start every simulation as zeros
+        for (int i = tid; i < 8 * PW_BYTES / 16; i += NTHREADS)
+            reinterpret_cast<uint4*>(scr + S_PW)[i] = make_uint4(0, 0, 0, 0);
+        if (tid < 8 * MAXIT * 2) tlist[tid] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");        // leaves written by the search lanes
+        __syncthreads();
+        if (wave == 0) {
+            // rank the games that need the network and deal them to the four SIMD pairs
+            const int gg = (int)blockIdx.x * gpw + lane;
+            bool need = false;
+            if (lane < gpw && gg < E.G) {
+                const int kind = leaf_info[gg] & 0xFF;
+                need = kind == AZ_LEAF_EVAL || kind == AZ_LEAF_ROOT;
+            }
+            const unsigned long long mask = __ballot(need);
+            const int total = __popcll(mask), rank = __popcll(mask & ((1ull << lane) - 1ull));
+            const int base = total >> 2, rem = total & 3;
+            if (need) {
+                const int big = rem * (base + 1);
+                int unit, pos;
+                if (rank < big) { unit = rank / (base + 1); pos = rank - unit * (base + 1); }
+                else { const int q = (rank - big) / base; unit = rem + q; pos = rank - big - q * base; }
+                const int len = base + (unit < rem), na = len - 2 * ((len + 1) >> 2);
+                const int w = unit + (pos < na ? 0 : 4), q = pos < na ? pos : pos - na;
+                tlist[w * MAXIT * 2 + q] = gg + 1;
+            }
+            if (lane == 0) {
+                const int len = base + (0 < rem), na = len - 2 * ((len + 1) >> 2);
+                wtot[0] = (na + 3) >> 2;
+            }
+        }
+        __syncthreads();
+        const int nrounds = wtot[0];
+        net_rounds(blob, num_blocks, leaf_bb, p, v, w1, w2, bufX, bufY, scr, nrounds, tid, wave, lane);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");        // (p, v) written by the head phase
+        __syncthreads();
+        if (sim + 1 < num_sims) search(T_{}, T_{});
+        else search(T_{}, F_{});
     }
 }
 
@@ -1116,6 +1231,33 @@ int az_sim_step(az_engine* e, float* p, float* v, uint64_t* leaf_bb, int32_t* le
     case 32: if constexpr (32 >= GroupSize<GM>::min_value) hipLaunchKernelGGL((k_sim_step_p<GM, 32, true, true>), gr_, dim3(BLOCK_THREADS), 0, (hipStream_t)stream, e->d, p, v, leaf_bb, leaf_info); break;
     case 64: if constexpr (64 >= GroupSize<GM>::min_value) hipLaunchKernelGGL((k_sim_step_p<GM, 64, true, true>), gr_, dim3(BLOCK_THREADS), 0, (hipStream_t)stream, e->d, p, v, leaf_bb, leaf_info); break;
   } });
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int az_c4_move_fused(az_engine* e, const uint8_t* blob, int32_t num_blocks, uint64_t* leaf_bb, int32_t* leaf_info,
+                     float* p, float* v, void* stream) {
+    if (!e || !blob || !leaf_bb || !leaf_info || !p || !v) return fail("null argument");
+    if (e->cfg.game != AZ_GAME_C4) return fail("az_c4_move_fused: Connect Four only");
+    if (num_blocks < 0) return fail("az_c4_move_fused: num_blocks");
+    if (e->d.S <= 0) return 0;
+    // games per workgroup: a multiple of 8 (whole lane groups), at most 64 (one search lane group per game)
+    const int cus = 256;
+    int gpw = ((e->d.G + cus - 1) / cus + 7) & ~7;
+    if (gpw > 64) return fail("az_c4_move_fused: at most 16384 games");
+    const int grid = (e->d.G + gpw - 1) / gpw;
+    static unsigned long long attr_done = 0;         // bit d = dynamic-LDS attribute set on device d
+    int dev_id = 0;
+    HIPCHK(hipGetDevice(&dev_id));
+    if (dev_id >= 64 || !((attr_done >> dev_id) & 1ull)) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_c4_move_fused),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        if (dev_id < 64) attr_done |= 1ull << dev_id;
+    }
+    Dev d = e->d;
+    d.cache = nullptr;                               // the evaluation cache is a feature of the two-kernel path
+    hipLaunchKernelGGL(k_c4_move_fused, dim3(grid), dim3(NTHREADS), LDS_BYTES, (hipStream_t)stream, d, blob,
+                       (int)num_blocks, leaf_bb, leaf_info, p, v, (int)e->d.S, gpw);
     LAUNCH_CHECK();
     return 0;
 }

@@ -61,6 +61,7 @@ class SelfPlayEngine:
             self.out_visits = torch.zeros(self.G, self.A, dtype=torch.int32, device=self.device)
             self.out_winner = torch.zeros(self.G, dtype=torch.int32, device=self.device)
         self._drain_buf = None
+        self._pv = None
 
     def close(self):
         if getattr(self, 'h', None):
@@ -130,6 +131,15 @@ class SelfPlayEngine:
             self._check_pv(p, v)
         check(self.lib.az_sim_step(self.h, ptr(p), ptr(v), ptr(self.leaf_bb), ptr(self.leaf_info), _stream()))
         return self.leaf_bb, self.leaf_info
+
+    def move_fused(self, net):
+        """All S simulations of the move in one launch with a FusedC4Net (after begin_move / apply_root)."""
+        if self._pv is None:
+            self._pv = (torch.zeros(self.G, self.A, dtype=torch.float32, device=self.device),
+                        torch.zeros(self.G, dtype=torch.float32, device=self.device))
+        p, v = self._pv
+        check(self.lib.az_c4_move_fused(self.h, ptr(net.blob), int(net.num_blocks), ptr(self.leaf_bb),
+                                        ptr(self.leaf_info), ptr(p), ptr(v), _stream()))
 
     def run_sims_uniform(self, num_sims):
         check(self.lib.az_run_sims_uniform(self.h, int(num_sims), _stream()))

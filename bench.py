@@ -135,6 +135,8 @@ def main():
                     help='log2 entries of the engine evaluation cache (0 = off, the default: every leaf goes '
                          'through the network as in the reference); the cache is invalidated every step, as '
                          'a weight update per move would')
+    ap.add_argument('--fused-move', action='store_true',
+                    help='all simulations of a move in one launch (az_c4_move_fused): a workgroup owns its games')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     args = ap.parse_args()
@@ -188,7 +190,7 @@ def main():
     if use_cache:
         eng.enable_eval_cache(args.eval_cache_log2)
     step_no = [0]
-    net_ev, tree_ev = [], []       # (start, end) HIP event pairs on the launch stream
+    net_ev, tree_ev, move_ev = [], [], []       # (start, end) HIP event pairs on the launch stream
 
     def timed(fn, sink, on):
         if not on:
@@ -217,6 +219,14 @@ def main():
             bb, info = eng.begin_move()
             p, _ = evaluate(bb, info)
             eng.apply_root(p)
+            if args.fused_move:
+                timed(lambda: eng.move_fused(fused), move_ev, measure)
+                eng.choose_and_advance()
+                if measure:
+                    raw = eng.drain_finished_bytes()
+                    if world > 1:
+                        gather_record_bytes(raw, dst=0, device='cpu' if rehearse else dev)
+                return
             bb, info = eng.select()
             for s in range(S):
                 sample = measure and (s % 16 == 7)      # every 16th launch carries event pairs
@@ -312,7 +322,9 @@ def main():
             except (OSError, KeyError, IndexError, ValueError):
                 return None
         bps = bytes_per_sim(d, f)
-        if net is not None and args.net_impl == 'hip':
+        if net is not None and args.net_impl == 'hip' and args.fused_move:
+            out['fused_move_ms'] = avg_ms(move_ev)
+        elif net is not None and args.net_impl == 'hip':
             ms = avg_ms(net_ev)
             # leaves one launch evaluates x flops per leaf; the 128-channel kernels take every leaf of
             # the batch, needed or not, and only the needed ones count as algorithmic work

@@ -235,6 +235,16 @@ int  az_c4net128_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uin
                               const int32_t* leaf_info, int32_t n, void* workspace, float* p, float* v,
                               void* stream);
 
+/* All S simulations of a move in ONE launch, Connect Four with the <= 32-channel network: replaces
+ * the S x { network, az_sim_step } loop above (selfplay.py:24-38 / mcts.py:119-158 between
+ * az_apply_root and az_choose_and_advance).  A workgroup owns its games for the whole move: search
+ * step, network for those games' leaves, search step, ... with workgroup barriers only.  blob as for
+ * az_c4net_bf16_forward; leaf_bb / leaf_info / p / v are the engine-sized DEVICE buffers of the
+ * stepwise calls (used as scratch between the phases).  Up to 16384 games per engine; the evaluation
+ * cache is not consulted.  Results are bit-identical to the stepwise loop with az_c4net_bf16_forward. */
+int  az_c4_move_fused(az_engine* e, const uint8_t* blob, int32_t num_blocks, uint64_t* leaf_bb,
+                      int32_t* leaf_info, float* p, float* v, void* stream);
+
 /* Tic-tac-toe network (alphazero/models.py:70-87 with shape_in [2,3,3], shape_out [9], as in
  * alphazero/config/tictactoe.yaml:4-11) entirely in fp32, one launch: stem, shared residual block x
  * num_blocks, policy head with soft-max over the empty squares (mcts.py:101-106), value head.

@@ -146,3 +146,45 @@ def test_cache_bad_size_rejected():
     eng.enable_eval_cache(12)
     eng.enable_eval_cache(0)
     eng.close()
+
+
+@pytest.mark.parametrize('G,S', [(512, 48), (8192, 24), (100, 33), (8, 20)])
+def test_fused_move_equals_the_stepwise_loop(G, S):
+    """az_c4_move_fused (a workgroup owns its games for the whole move, search and network in one launch)
+    against the stepwise loop with az_c4net_bf16_forward: identical moves, visit counts, records, counters."""
+    from alphazero_amd import engine as E
+    from alphazero_amd.models import AlphaZeroC4
+    from alphazero_amd.net import FusedC4Net
+    torch.manual_seed(8)
+    model = AlphaZeroC4(6, 32).eval().cuda()
+    net = FusedC4Net.from_module(model, 'cuda')
+    out = []
+    for fused in (False, True):
+        eng = E.SelfPlayEngine(E._lib.GAME_C4, G, S, exploration_depth=4, reuse_search_tree=True, seed=21, device=0)
+        res = []
+        for mv in range(10):
+            bb, info = eng.begin_move()
+            p, _ = net(bb, info)
+            eng.apply_root(p)
+            if fused:
+                eng.move_fused(net)
+            else:
+                bb, info = eng.select()
+                for s in range(S):
+                    p, v = net(bb, info)
+                    if s < S - 1:
+                        bb, info = eng.sim_step(p, v)
+                    else:
+                        eng.expand_backup(p, v)
+            a, ne, vis, w = eng.choose_and_advance()
+            res.append((a.cpu().numpy().copy(), vis.cpu().numpy().copy(), w.cpu().numpy().copy()))
+        recs = eng.drain_finished_bytes().copy()
+        recs = recs[np.argsort(recs[:, :8].copy().view(np.uint64)[:, 0])]
+        out.append((res, eng.stats(), recs))
+        eng.close()
+    for (a0, v0, w0), (a1, v1, w1) in zip(out[0][0], out[1][0]):
+        np.testing.assert_array_equal(a0, a1)
+        np.testing.assert_array_equal(v0, v1)
+        np.testing.assert_array_equal(w0, w1)
+    assert out[0][1] == out[1][1]
+    np.testing.assert_array_equal(out[0][2], out[1][2])
