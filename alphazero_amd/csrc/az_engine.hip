@@ -815,6 +815,12 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
     using T_ = std::true_type;
     using F_ = std::false_type;
 
+#ifdef AZ_EXP_TIMING
+    long long t_tree = 0, t_list = 0, t_net = 0, t0 = clock64(), t1;
+#define TICK(acc) do { t1 = clock64(); acc += t1 - t0; t0 = t1; } while (0)
+#else
+#define TICK(acc) do { } while (0)
+#endif
     search(F_{}, T_{});
     for (int sim = 0; sim < num_sims; ++sim) {
         // the planes of the head phase and the task list start every simulation as zeros
@@ -823,6 +829,7 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
         if (tid < 8 * MAXIT * 2) tlist[tid] = 0;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");        // leaves written by the search lanes
         __syncthreads();
+        TICK(t_tree);
         if (wave == 0) {
             // rank the games that need the network and deal them to the four SIMD pairs
             const int gg = (int)blockIdx.x * gpw + lane;
@@ -850,12 +857,26 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
         }
         __syncthreads();
         const int nrounds = wtot[0];
+        TICK(t_list);
+#ifndef AZ_EXP_SKIP_NET
         net_rounds(blob, num_blocks, leaf_bb, p, v, w1, w2, bufX, bufY, scr, nrounds, tid, wave, lane);
+#endif
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");        // (p, v) written by the head phase
         __syncthreads();
+        TICK(t_net);
         if (sim + 1 < num_sims) search(T_{}, T_{});
         else search(T_{}, F_{});
     }
+#ifdef AZ_EXP_TIMING
+    if (tid == 0) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(E.ring_count + 16);
+        atomicAdd(dbg + 0, (unsigned long long)t_tree);
+        atomicAdd(dbg + 1, (unsigned long long)t_list);
+        atomicAdd(dbg + 2, (unsigned long long)t_net);
+        atomicAdd(dbg + 3, 1ull);
+    }
+#endif
+#undef TICK
 }
 
 // num_sims whole simulations per game in one launch, UniformModel evaluated in place
@@ -1235,15 +1256,24 @@ int az_sim_step(az_engine* e, float* p, float* v, uint64_t* leaf_bb, int32_t* le
     return 0;
 }
 
+#ifdef AZ_EXP_TIMING
+int az_debug_counters(az_engine* e, unsigned long long* out4) {
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out4, e->d.ring_count + 16, 32, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(e->d.ring_count + 16, 0, 32));
+    return 0;
+}
+#endif
+
 int az_c4_move_fused(az_engine* e, const uint8_t* blob, int32_t num_blocks, uint64_t* leaf_bb, int32_t* leaf_info,
                      float* p, float* v, void* stream) {
     if (!e || !blob || !leaf_bb || !leaf_info || !p || !v) return fail("null argument");
     if (e->cfg.game != AZ_GAME_C4) return fail("az_c4_move_fused: Connect Four only");
     if (num_blocks < 0) return fail("az_c4_move_fused: num_blocks");
     if (e->d.S <= 0) return 0;
-    // games per workgroup: a multiple of 8 (whole lane groups), at most 64 (one search lane group per game)
+    // games per workgroup: spread over one workgroup per CU, at most 64 (eight search lanes per game)
     const int cus = 256;
-    int gpw = ((e->d.G + cus - 1) / cus + 7) & ~7;
+    const int gpw = (e->d.G + cus - 1) / cus;
     if (gpw > 64) return fail("az_c4_move_fused: at most 16384 games");
     const int grid = (e->d.G + gpw - 1) / gpw;
     static unsigned long long attr_done = 0;         // bit d = dynamic-LDS attribute set on device d

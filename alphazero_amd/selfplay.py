@@ -67,6 +67,11 @@ class SelfPlayWorker:
             if self._fused is None and evaluator is None:
                 raise ValueError('eval_cache_log2 needs one of the HIP networks (or a caller-supplied evaluator)')
             self.engine.enable_eval_cache(eval_cache_log2)
+        # Connect Four with the <= 32-channel network: a whole move's simulations run in one launch
+        # (az_c4_move_fused); the evaluation cache belongs to the per-simulation path
+        from .net import FusedC4Net as _F
+        self._fused_move = (isinstance(self._fused, _F) and evaluator is None and not eval_cache_log2
+                            and self.num_games <= 16384)
         self._version = 0
         self.positions = 0
         self.games_finished = 0
@@ -89,7 +94,9 @@ class SelfPlayWorker:
             bb, info = eng.begin_move()
             p, _ = self._eval(bb, info)
             eng.apply_root(p)
-            if S > 0:
+            if S > 0 and self._fused_move and self._fused is not None:
+                eng.move_fused(self._fused)            # all S simulations, search and network, in one launch
+            elif S > 0:
                 bb, info = eng.select()
                 for _ in range(S - 1):
                     p, v = self._eval(bb, info)

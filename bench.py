@@ -135,8 +135,10 @@ def main():
                     help='log2 entries of the engine evaluation cache (0 = off, the default: every leaf goes '
                          'through the network as in the reference); the cache is invalidated every step, as '
                          'a weight update per move would')
-    ap.add_argument('--fused-move', action='store_true',
-                    help='all simulations of a move in one launch (az_c4_move_fused): a workgroup owns its games')
+    ap.add_argument('--stepwise', action='store_true',
+                    help='one network launch and one search launch per simulation instead of az_c4_move_fused '
+                         '(all simulations of a move in one launch, a workgroup owns its games), which is the '
+                         'default for the <= 32-channel HIP network up to 16384 games')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     args = ap.parse_args()
@@ -187,6 +189,9 @@ def main():
             evaluate = lambda bb, info: evaluate_leaves(eng.game, net, bb, info)
 
     use_cache = args.eval_cache_log2 > 0 and net is not None and args.net_impl == 'hip'
+    fused_move = (net is not None and args.net_impl == 'hip' and args.model == 'c4_6x32' and not args.stepwise
+                  and not use_cache and G <= 16384)
+    stepwise_now = [not fused_move]       # the untimed sampling steps after the timed region flip this
     if use_cache:
         eng.enable_eval_cache(args.eval_cache_log2)
     step_no = [0]
@@ -219,7 +224,7 @@ def main():
             bb, info = eng.begin_move()
             p, _ = evaluate(bb, info)
             eng.apply_root(p)
-            if args.fused_move:
+            if not stepwise_now[0]:
                 timed(lambda: eng.move_fused(fused), move_ev, measure)
                 eng.choose_and_advance()
                 if measure:
@@ -271,6 +276,13 @@ def main():
     elapsed = time.perf_counter() - t0
     st1 = eng.stats()
     hits = (eng.eval_cache_hits() - hits0) if use_cache else 0
+    if fused_move and world == 1:
+        # untimed, single-GPU runs only: two moves through the per-simulation kernels, for their own durations (the search
+        # kernel against HBM, the network kernel against the matrix cores)
+        stepwise_now[0] = True
+        for _ in range(2):
+            one_step(True)
+        torch.cuda.synchronize()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -299,6 +311,7 @@ def main():
                                f'reuse_search_tree, model {args.model}, {args.mix_moves} age-mixing moves + '
                                f'{args.preroll} pre-roll moves',
                    'games_per_gpu': G, 'sims_per_move': S, 'net': args.model,
+                   'launches': 'one per move (az_c4_move_fused)' if fused_move else 'per simulation',
                    'net_impl': None if net is None else args.net_impl, 'preroll_moves': args.preroll,
                    'mix_moves': args.mix_moves,
                    'mean_select_depth': d, 'leaf_eval_fraction': f,
@@ -322,9 +335,19 @@ def main():
             except (OSError, KeyError, IndexError, ValueError):
                 return None
         bps = bytes_per_sim(d, f)
-        if net is not None and args.net_impl == 'hip' and args.fused_move:
-            out['fused_move_ms'] = avg_ms(move_ev)
-        elif net is not None and args.net_impl == 'hip':
+        if fused_move:
+            # the whole move is one launch: its matrix-core work is the leaves evaluated in the move
+            ms = avg_ms(move_ev)
+            fl = trunk_flops_per_leaf(blocks, ch) * evals / args.steps
+            tf = fl / (ms * 1e-3) / 1e12
+            out['roofline'] = {'kernel': 'k_c4_move_fused', 'bound': 'mfma', 'achieved': tf, 'peak': BF16_PEAK_TFLOPS,
+                               'unit': 'TFLOP/s', 'frac': tf / BF16_PEAK_TFLOPS,
+                               'traffic': pmc_traffic('k_c4_move_fused'), 'avg_launch_ms': ms,
+                               'flops_per_leaf': trunk_flops_per_leaf(blocks, ch),
+                               'leaves_per_launch': evals / args.steps,
+                               'note': 'search and network phases of all simulations of a move; the search phases '
+                                       'do no matrix work'}
+        if net is not None and args.net_impl == 'hip':
             ms = avg_ms(net_ev)
             # leaves one launch evaluates x flops per leaf; the 128-channel kernels take every leaf of
             # the batch, needed or not, and only the needed ones count as algorithmic work
@@ -332,7 +355,8 @@ def main():
             fl = trunk_flops_per_leaf(blocks, ch) * f_net * G
             tf = fl / (ms * 1e-3) / 1e12
             kname = 'k_c4net_bf16' if ch <= 32 else 'k_stem128 + k_tower128 + k_heads128'
-            out['roofline'] = {'kernel': kname, 'bound': 'mfma', 'achieved': tf, 'peak': BF16_PEAK_TFLOPS,
+            out['roofline_stepwise_net' if fused_move else 'roofline'] = {
+                               'kernel': kname, 'bound': 'mfma', 'achieved': tf, 'peak': BF16_PEAK_TFLOPS,
                                'unit': 'TFLOP/s', 'frac': tf / BF16_PEAK_TFLOPS,
                                'traffic': pmc_traffic('k_c4net_bf16') if ch <= 32 else None,
                                'avg_launch_ms': ms, 'flops_per_leaf': trunk_flops_per_leaf(blocks, ch),

@@ -1,0 +1,22 @@
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from alphazero_amd import engine as E
+from alphazero_amd.models import AlphaZeroC4
+from alphazero_amd.net import FusedC4Net
+G, S = 8192, 800
+eng = E.SelfPlayEngine(E._lib.GAME_C4, G, S, exploration_depth=4, reuse_search_tree=True, seed=0, device=0)
+torch.manual_seed(0)
+net = FusedC4Net.from_module(AlphaZeroC4(6, 32).eval().cuda(), 'cuda')
+for i in range(160):
+    eng.begin_move_uniform(); eng.run_sims_uniform(S); eng.choose_and_advance()
+    if i % 2: eng.drain_finished()
+out = (C.c_ulonglong * 4)()
+for i in range(12):
+    bb, info = eng.begin_move(); p, _ = net(bb, info); eng.apply_root(p)
+    eng.lib.az_debug_counters(eng.h, out)
+    eng.move_fused(net)
+    eng.choose_and_advance(); eng.drain_finished()
+    eng.lib.az_debug_counters(eng.h, out)
+    n = out[3]
+    print(f'move {i}: per WG per sim, shader cycles: tree {out[0]/n/S:.0f}  list {out[1]/n/S:.0f}  net {out[2]/n/S:.0f}  (WGs {n})')
