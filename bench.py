@@ -329,9 +329,12 @@ def main():
             FETCH_SIZE doubled, the gfx950 correction for 16-byte-per-lane reads)."""
             try:
                 pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_means.json')))
-                fe = [v['FETCH_SIZE']['mean'] for k, v in pm['pmc_fetch'].items() if k.startswith(kernel_prefix)]
-                wr = [v['WRITE_SIZE']['mean'] for k, v in pm['pmc_write'].items() if k.startswith(kernel_prefix)]
-                return (2.0 * fe[0] + wr[0]) * 1024.0
+                for fk, wk in (('pmc_fetch', 'pmc_write'), ('pmc_stepwise_fetch', 'pmc_stepwise_write')):
+                    fe = [v['FETCH_SIZE']['mean'] for k, v in pm.get(fk, {}).items() if k.startswith(kernel_prefix)]
+                    wr = [v['WRITE_SIZE']['mean'] for k, v in pm.get(wk, {}).items() if k.startswith(kernel_prefix)]
+                    if fe and wr:
+                        return (2.0 * fe[0] + wr[0]) * 1024.0
+                return None
             except (OSError, KeyError, IndexError, ValueError):
                 return None
         bps = bytes_per_sim(d, f)

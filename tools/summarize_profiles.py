@@ -12,7 +12,7 @@ import sys
 out = sys.argv[1]
 summ = os.path.join(out, 'summary')
 os.makedirs(summ, exist_ok=True)
-for name in ('bench_net', 'bench_net_cache', 'bench_uniform', 'net128'):
+for name in ('bench_net', 'bench_net_stepwise', 'bench_net_cache', 'bench_uniform', 'net128'):
     for f in glob.glob(os.path.join(out, name, '*', '*kernel_stats.csv')):
         shutil.copy(f, os.path.join(summ, f'{name}_kernel_stats.csv'))
     log = os.path.join(out, name + '.log')
@@ -29,6 +29,6 @@ for d in sorted(glob.glob(os.path.join(out, 'pmc*'))):
             agg[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
     pmc[os.path.basename(d)] = {
         k.split('(')[0][:80]: {c: {'launches': len(x), 'mean': sum(x) / len(x)} for c, x in v.items()}
-        for k, v in agg.items() if any(s in k for s in ('k_sim_step', 'k_c4net', 'k_tower128', 'k_run_uniform', 'k_stem128', 'k_heads128'))}
+        for k, v in agg.items() if any(s in k for s in ('k_sim_step', 'k_c4net', 'k_c4_move_fused', 'k_tower128', 'k_run_uniform', 'k_stem128', 'k_heads128'))}
 json.dump(pmc, open(os.path.join(summ, 'pmc_means.json'), 'w'), indent=1, sort_keys=True)
 print(json.dumps(pmc, indent=1, sort_keys=True)[:6000])
