@@ -1158,6 +1158,10 @@ int az_set_model_version(az_engine* e, int32_t version) {
     return 0;
 }
 
+// hit counters: one per wavefront of any search grid (G / 8 trees per wave at least, 8 waves per
+// workgroup of the one-launch-per-move kernel, whose grid never exceeds G workgroups)
+static size_t cache_counters(int G) { return (size_t)8 * G + 8; }
+
 int az_eval_cache_enable(az_engine* e, int32_t log2_entries) {
     if (!e) return fail("null engine");
     if (log2_entries != 0 && (log2_entries < 10 || log2_entries > 28)) return fail("eval cache: log2_entries must be 0 or 10..28");
@@ -1167,7 +1171,7 @@ int az_eval_cache_enable(az_engine* e, int32_t log2_entries) {
     e->d.cache = nullptr; e->d.cache_mask = 0; e->d.cache_hits = nullptr;
     if (log2_entries == 0) return 0;
     const size_t bytes = ((size_t)1 << log2_entries) * 64;
-    const size_t counters = (size_t)e->d.G + WAVES_PER_BLOCK;       // >= wavefronts of any search grid
+    const size_t counters = cache_counters(e->d.G);
     uint4* t = nullptr;
     unsigned long long* c = nullptr;
     hipError_t err = hipMalloc(&t, bytes);
@@ -1184,7 +1188,7 @@ int az_eval_cache_hits(az_engine* e, uint64_t* hits, void* stream) {
     if (!e || !hits) return fail("null argument");
     *hits = 0;
     if (!e->d.cache_hits) return 0;
-    std::vector<unsigned long long> h((size_t)e->d.G + WAVES_PER_BLOCK);
+    std::vector<unsigned long long> h(cache_counters(e->d.G));
     HIPCHK(hipMemcpyAsync(h.data(), e->d.cache_hits, h.size() * 8, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     for (unsigned long long x : h) *hits += x;
@@ -1284,9 +1288,7 @@ int az_c4_move_fused(az_engine* e, const uint8_t* blob, int32_t num_blocks, uint
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         if (dev_id < 64) attr_done |= 1ull << dev_id;
     }
-    Dev d = e->d;
-    d.cache = nullptr;                               // the evaluation cache is a feature of the two-kernel path
-    hipLaunchKernelGGL(k_c4_move_fused, dim3(grid), dim3(NTHREADS), LDS_BYTES, (hipStream_t)stream, d, blob,
+    hipLaunchKernelGGL(k_c4_move_fused, dim3(grid), dim3(NTHREADS), LDS_BYTES, (hipStream_t)stream, e->d, blob,
                        (int)num_blocks, leaf_bb, leaf_info, p, v, (int)e->d.S, gpw);
     LAUNCH_CHECK();
     return 0;

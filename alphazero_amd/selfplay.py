@@ -68,10 +68,9 @@ class SelfPlayWorker:
                 raise ValueError('eval_cache_log2 needs one of the HIP networks (or a caller-supplied evaluator)')
             self.engine.enable_eval_cache(eval_cache_log2)
         # Connect Four with the <= 32-channel network: a whole move's simulations run in one launch
-        # (az_c4_move_fused); the evaluation cache belongs to the per-simulation path
+        # (az_c4_move_fused)
         from .net import FusedC4Net as _F
-        self._fused_move = (isinstance(self._fused, _F) and evaluator is None and not eval_cache_log2
-                            and self.num_games <= 16384)
+        self._fused_move = isinstance(self._fused, _F) and evaluator is None and self.num_games <= 16384
         self._version = 0
         self.positions = 0
         self.games_finished = 0

@@ -190,7 +190,7 @@ def main():
 
     use_cache = args.eval_cache_log2 > 0 and net is not None and args.net_impl == 'hip'
     fused_move = (net is not None and args.net_impl == 'hip' and args.model == 'c4_6x32' and not args.stepwise
-                  and not use_cache and G <= 16384)
+                  and G <= 16384)
     stepwise_now = [not fused_move]       # the untimed sampling steps after the timed region flip this
     if use_cache:
         eng.enable_eval_cache(args.eval_cache_log2)
@@ -341,13 +341,13 @@ def main():
         if fused_move:
             # the whole move is one launch: its matrix-core work is the leaves evaluated in the move
             ms = avg_ms(move_ev)
-            fl = trunk_flops_per_leaf(blocks, ch) * evals / args.steps
+            fl = trunk_flops_per_leaf(blocks, ch) * (evals - hits) / args.steps
             tf = fl / (ms * 1e-3) / 1e12
             out['roofline'] = {'kernel': 'k_c4_move_fused', 'bound': 'mfma', 'achieved': tf, 'peak': BF16_PEAK_TFLOPS,
                                'unit': 'TFLOP/s', 'frac': tf / BF16_PEAK_TFLOPS,
                                'traffic': pmc_traffic('k_c4_move_fused'), 'avg_launch_ms': ms,
                                'flops_per_leaf': trunk_flops_per_leaf(blocks, ch),
-                               'leaves_per_launch': evals / args.steps,
+                               'leaves_per_launch': (evals - hits) / args.steps,
                                'note': 'search and network phases of all simulations of a move; the search phases '
                                        'do no matrix work'}
         if net is not None and args.net_impl == 'hip':

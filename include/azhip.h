@@ -241,7 +241,7 @@ int  az_c4net128_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uin
  * step, network for those games' leaves, search step, ... with workgroup barriers only.  blob as for
  * az_c4net_bf16_forward; leaf_bb / leaf_info / p / v are the engine-sized DEVICE buffers of the
  * stepwise calls (used as scratch between the phases).  Up to 16384 games per engine; the evaluation
- * cache is not consulted.  Results are bit-identical to the stepwise loop with az_c4net_bf16_forward. */
+ * cache is used when enabled.  Results are bit-identical to the stepwise loop with az_c4net_bf16_forward. */
 int  az_c4_move_fused(az_engine* e, const uint8_t* blob, int32_t num_blocks, uint64_t* leaf_bb,
                       int32_t* leaf_info, float* p, float* v, void* stream);
 

@@ -159,8 +159,11 @@ def test_fused_move_equals_the_stepwise_loop(G, S):
     model = AlphaZeroC4(6, 32).eval().cuda()
     net = FusedC4Net.from_module(model, 'cuda')
     out = []
-    for fused in (False, True):
+    hits = 0
+    for fused in (False, True, 'cache'):
         eng = E.SelfPlayEngine(E._lib.GAME_C4, G, S, exploration_depth=4, reuse_search_tree=True, seed=21, device=0)
+        if fused == 'cache':
+            eng.enable_eval_cache(16)
         res = []
         for mv in range(10):
             bb, info = eng.begin_move()
@@ -181,10 +184,14 @@ def test_fused_move_equals_the_stepwise_loop(G, S):
         recs = eng.drain_finished_bytes().copy()
         recs = recs[np.argsort(recs[:, :8].copy().view(np.uint64)[:, 0])]
         out.append((res, eng.stats(), recs))
+        if fused == 'cache':
+            hits = eng.eval_cache_hits()
         eng.close()
-    for (a0, v0, w0), (a1, v1, w1) in zip(out[0][0], out[1][0]):
-        np.testing.assert_array_equal(a0, a1)
-        np.testing.assert_array_equal(v0, v1)
-        np.testing.assert_array_equal(w0, w1)
-    assert out[0][1] == out[1][1]
-    np.testing.assert_array_equal(out[0][2], out[1][2])
+    for other in (1, 2):                               # one launch per move; the same with the evaluation cache
+        for (a0, v0, w0), (a1, v1, w1) in zip(out[0][0], out[other][0]):
+            np.testing.assert_array_equal(a0, a1)
+            np.testing.assert_array_equal(v0, v1)
+            np.testing.assert_array_equal(w0, w1)
+        assert out[0][1] == out[other][1]
+        np.testing.assert_array_equal(out[0][2], out[other][2])
+    assert hits > 0
