@@ -815,7 +815,7 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
     using T_ = std::true_type;
     using F_ = std::false_type;
 
-#ifdef AZ_EXP_TIMING
+#ifdef AZ_EXP_TIMING     // tuning aid (tools/exp_fused_timing.py): shader cycles per phase, summed over workgroups
     long long t_tree = 0, t_list = 0, t_net = 0, t0 = clock64(), t1;
 #define TICK(acc) do { t1 = clock64(); acc += t1 - t0; t0 = t1; } while (0)
 #else
@@ -858,9 +858,7 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
         __syncthreads();
         const int nrounds = wtot[0];
         TICK(t_list);
-#ifndef AZ_EXP_SKIP_NET
         net_rounds(blob, num_blocks, leaf_bb, p, v, w1, w2, bufX, bufY, scr, nrounds, tid, wave, lane);
-#endif
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");        // (p, v) written by the head phase
         __syncthreads();
         TICK(t_net);

@@ -1,3 +1,9 @@
+#!/usr/bin/env python3
+"""Phase split of the one-launch-per-move kernel (tuning aid).  Needs a library built with the cycle
+counters compiled in:
+    make -C alphazero_amd/csrc HIPFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -DAZ_EXP_TIMING"
+and prints, per move, the shader cycles a workgroup spends per simulation in the search phase, in
+ranking its leaves and in the network phase.  Rebuild without the flag afterwards."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
