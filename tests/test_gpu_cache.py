@@ -1,6 +1,7 @@
-"""Evaluation cache of the engine: a leaf answered from the table must give the search exactly what
-the evaluator would have given it, so every move, visit count and finished game is identical with the
-cache on and off (the reference evaluates every leaf: alphazero/mcts.py:139-142)."""
+"""Two engine features that must not change a single visit count: the evaluation cache (a leaf answered
+from the table gives the search exactly what the evaluator would have given it; the reference evaluates
+every leaf: alphazero/mcts.py:139-142) and the one-launch-per-move kernel az_c4_move_fused (a workgroup
+owns its games; same trees as the stepwise calls), alone, together and at the benchmark's full size."""
 import numpy as np
 import pytest
 import torch
@@ -195,3 +196,45 @@ def test_fused_move_equals_the_stepwise_loop(G, S):
         assert out[0][1] == out[other][1]
         np.testing.assert_array_equal(out[0][2], out[other][2])
     assert hits > 0
+
+
+def test_full_size_move_properties():
+    """The benchmark's own shape (8 192 games x 800 simulations, 6x32 network, one launch per move): the
+    size-independent properties of a search -- every simulation is accounted for, a fresh root's visit
+    counts sum to S and a re-used root's to at least S, no pool is exhausted -- and the stepwise loop
+    agrees bit for bit on the last move."""
+    from alphazero_amd import engine as E
+    from alphazero_amd.models import AlphaZeroC4
+    from alphazero_amd.net import FusedC4Net
+    G, S = 8192, 800
+    torch.manual_seed(0)
+    net = FusedC4Net.from_module(AlphaZeroC4(6, 32).eval().cuda(), 'cuda')
+    engs = [E.SelfPlayEngine(E._lib.GAME_C4, G, S, exploration_depth=4, reuse_search_tree=True, seed=3, device=0)
+            for _ in range(2)]
+    last = []
+    for k, eng in enumerate(engs):
+        for mv in range(3):
+            bb, info = eng.begin_move()
+            fresh = ((info & 0xFF) == 3).cpu().numpy()                   # roots that had to be expanded
+            p, _ = net(bb, info)
+            eng.apply_root(p)
+            if k == 0 or mv < 2:
+                eng.move_fused(net)
+            else:
+                bb, info = eng.select()
+                for s in range(S):
+                    p, v = net(bb, info)
+                    if s < S - 1:
+                        bb, info = eng.sim_step(p, v)
+                    else:
+                        eng.expand_backup(p, v)
+            a, ne, vis, w = eng.choose_and_advance()
+            tot = vis.sum(dim=1).cpu().numpy()
+            assert np.all(tot[fresh] == S) and np.all(tot[~fresh] >= S)
+            assert np.all((a.cpu().numpy() >= 0) & (a.cpu().numpy() < 7))
+        st = eng.stats()
+        assert st['sims'] == G * S * 3 and st['errors'] == 0 and st['moves'] == G * 3
+        last.append((a.cpu().numpy().copy(), vis.cpu().numpy().copy()))
+        eng.close()
+    np.testing.assert_array_equal(last[0][0], last[1][0])
+    np.testing.assert_array_equal(last[0][1], last[1][1])
