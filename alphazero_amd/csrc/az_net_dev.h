@@ -85,9 +85,10 @@ __device__ __forceinline__ f32x16 bias_acc(const float* bias, int h) {
 // v_cvt_pk_bf16_f32 and one v_pk_max_i16 per pair instead of two v_max_f32 per value
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(2))) short s16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 __device__ __forceinline__ uint32_t relu_bf16x2(float a, float b) {
-    bf16x2 y;
-    y[0] = (__bf16)a; y[1] = (__bf16)b;
+    const f32x2 f = {a, b};
+    const bf16x2 y = __builtin_convertvector(f, bf16x2);     // one v_cvt_pk_bf16_f32 for the pair
     const s16x2 z = {0, 0};
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, y), z));
 }
