@@ -28,7 +28,7 @@ class EngineConfig(C.Structure):
 
 class GameRecord(C.Structure):
     _fields_ = [('uid', C.c_uint64), ('num_moves', C.c_int32), ('winner', C.c_int32),
-                ('model_version', C.c_int32), ('reserved', C.c_int32),
+                ('model_version', C.c_int32), ('first_model_version', C.c_int32),
                 ('history', C.c_uint8 * (MAX_MOVES + 6)), ('num_edges', C.c_uint8 * (MAX_MOVES + 6)),
                 ('visits', (C.c_uint32 * MAX_ACTIONS) * MAX_MOVES)]
 
@@ -59,7 +59,9 @@ SIGNATURES = {
     'az_begin_move_uniform': (C.c_int, [_P, _P, _P]),
     'az_choose_and_advance': (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     'az_drain_finished': (C.c_int, [_P, C.POINTER(GameRecord), C.c_int32, C.POINTER(C.c_int32), _P]),
+    'az_take_finished_device': (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     'az_get_stats': (C.c_int, [_P, C.POINTER(Stats), _P]),
+    'az_engine_error_flags': (C.c_int, [_P]),
     'az_set_position': (C.c_int, [_P, C.c_int32, C.c_uint64, C.c_uint64, C.c_int32, _P, C.c_int32, C.c_uint32]),
     'az_get_tree': (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]),
     'az_node_words': (C.c_int, [_P]),

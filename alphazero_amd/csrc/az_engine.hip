@@ -33,6 +33,7 @@
 #include "../../include/azhip.h"
 #include "az_games.h"
 #include "az_net_dev.h"
+#include "az_host.h"
 
 #define WAVES_PER_BLOCK 4
 #define BLOCK_THREADS (64 * WAVES_PER_BLOCK)
@@ -40,12 +41,12 @@
 #define HIST_PAD (AZ_MAX_MOVES + 6)
 
 static thread_local std::string g_err;
-static int fail(const char* what, hipError_t e = hipSuccess) {
+int az_fail(const char* what, hipError_t e) {
     g_err = what;
     if (e != hipSuccess) { g_err += ": "; g_err += hipGetErrorString(e); }
     return -1;
 }
-#define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(#x, _e); } while (0)
+#define HIPCHK(x) AZ_HIPCHK(x)
 
 // ---------------------------------------------------------------------------
 // device-side state
@@ -62,7 +63,7 @@ struct __attribute__((aligned(128))) Slot {
     // counters, 64 B
     uint64_t st_sims, st_steps, st_evals, st_root_evals, st_moves, st_games;
     uint64_t uid;
-    int32_t  leaf_nm, pad0;
+    int32_t  leaf_nm, first_version; // model version when this game started
     uint32_t path[PATH_LEN];         // (node << 4) | slot per select level
     uint8_t  hist[HIST_PAD];
     uint8_t  nedges[HIST_PAD];
@@ -91,8 +92,28 @@ struct az_engine {
     az_engine_config cfg;
     Dev d;
     int A;
+    int num_cus;        // compute units of cfg.device
+    uint32_t err_flags; // error bits seen by the last az_drain_finished
     double2* lut_dev;
 };
+
+// Every entry point that takes an engine runs with the engine's device current and puts the caller's device
+// back on return: kernels are launched on the device that owns the pools, whatever device the calling thread
+// had selected (the stream argument must belong to the engine's device).
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceScope(int dev) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) { err = hipSetDevice(dev); switched = err == hipSuccess; }
+    }
+    ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
+};
+#define ENGINE_SCOPE(e)                                                        \
+    if (!(e)) return az_fail("null engine");                                   \
+    DeviceScope _scope((e)->cfg.device);                                       \
+    if (_scope.err != hipSuccess) return az_fail("selecting the engine's device", _scope.err)
 
 // ---------------------------------------------------------------------------
 // wave helpers
@@ -297,7 +318,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_reset(Dev E) {
         s->uid = E.first_uid + (uint64_t)g;
         s->root = AZ_NO_NODE; s->alloc = 0;
         s->leaf_kind = AZ_LEAF_NONE; s->leaf_depth = 0; s->leaf_nm = 0; s->leaf_nx = 0; s->leaf_pv = 0;
-        s->err = 0; s->move_sims = 0;
+        s->err = 0; s->move_sims = 0; s->first_version = E.version;
         s->st_sims = s->st_steps = s->st_evals = s->st_root_evals = s->st_moves = s->st_games = 0;
     }
 }
@@ -359,6 +380,9 @@ k_choose(Dev E, const double* u_in, int32_t* out_action, int32_t* out_nedges, ui
     WAVE_PROLOGUE
     constexpr int AS = GM::A + 1;
     const uint32_t root = s->root;
+    // pool exhaustion (bit 0) / record ring overflow (bit 1) of any game since the last reset: one word next
+    // to the ring counter, fetched by az_drain_finished together with it
+    if (lane == 0 && s->err) atomicOr(E.ring_count + 1, s->err);
     uint64_t nx = s->nx, pv = s->pv;
     int nm = s->nm;
     if (root == AZ_NO_NODE) {   // nothing searched (terminal or never begun): report and leave
@@ -435,7 +459,8 @@ k_choose(Dev E, const double* u_in, int32_t* out_action, int32_t* out_nedges, ui
         if (pos < E.ring_cap) {
             az_game_record* r = E.ring + pos;
             if (lane == 0) {
-                r->uid = s->uid; r->num_moves = nm; r->winner = w; r->model_version = E.version; r->reserved = 0;
+                r->uid = s->uid; r->num_moves = nm; r->winner = w; r->model_version = E.version;
+                r->first_model_version = s->first_version;
             }
             if (lane < HIST_PAD) { r->history[lane] = s->hist[lane]; r->num_edges[lane] = s->nedges[lane]; }
             const uint32_t* src = E.rec_visits + (size_t)g * AZ_MAX_MOVES * AZ_MAX_ACTIONS;
@@ -444,7 +469,8 @@ k_choose(Dev E, const double* u_in, int32_t* out_action, int32_t* out_nedges, ui
                 dst[i] = (i < nm * AZ_MAX_ACTIONS) ? src[i] : 0u;
         }
         if (lane == 0) {
-            if (pos >= E.ring_cap) s->err |= 2u;
+            if (pos >= E.ring_cap) { s->err |= 2u; atomicOr(E.ring_count + 1, 2u); }
+            s->first_version = E.version;
             s->nx = 0; s->pv = 0; s->nm = 0; s->root = AZ_NO_NODE; s->alloc = 0;
             s->uid += E.uid_stride;
             s->st_moves += 1; s->st_games += 1; s->leaf_kind = AZ_LEAF_NONE; s->move_sims = 0;
@@ -1045,6 +1071,24 @@ __global__ void k_ucb(Dev E, const uint32_t* N, const float* W, const float* P, 
     argmax[i] = best;
 }
 
+// finished-game records from the ring to a caller's device buffer, 16 bytes per thread; head_out = {records
+// copied, error bits}.  The ring counter is reset by the host code after this kernel, in stream order.
+__global__ void __launch_bounds__(256)
+k_take_finished(const az_game_record* __restrict__ ring, const uint32_t* __restrict__ ring_count, uint32_t ring_cap,
+                az_game_record* __restrict__ out, uint32_t max_records, int32_t* __restrict__ head_out) {
+    static_assert(sizeof(az_game_record) % 16 == 0, "records are copied as 16-byte words");
+    constexpr uint32_t WORDS = sizeof(az_game_record) / 16;
+    uint32_t count = ring_count[0], flags = ring_count[1];
+    if (count > ring_cap) count = ring_cap;
+    if (count > max_records) { count = max_records; flags |= 2u; }       // the rest is dropped: report it
+    const uint4* src = reinterpret_cast<const uint4*>(ring);
+    uint4* dst = reinterpret_cast<uint4*>(out);
+    const size_t total = (size_t)count * WORDS;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { head_out[0] = (int32_t)count; head_out[1] = (int32_t)flags; }
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -1065,33 +1109,61 @@ static inline dim3 group_grid(int G, int gs) {
     const int per_block = WAVES_PER_BLOCK * (64 / gs);
     return dim3((G + per_block - 1) / per_block);
 }
-#define LAUNCH_CHECK() do { hipError_t _e = hipGetLastError(); if (_e != hipSuccess) return fail("kernel launch", _e); } while (0)
+#define LAUNCH_CHECK() do { hipError_t _e = hipGetLastError(); if (_e != hipSuccess) return az_fail("kernel launch", _e); } while (0)
 #define DISPATCH_GAME(game, ...)                                   \
     do {                                                           \
         if ((game) == AZ_GAME_C4) { using GM = GameC4; __VA_ARGS__; } \
         else if ((game) == AZ_GAME_TTT) { using GM = GameTTT; __VA_ARGS__; } \
-        else return fail("unknown game id");                       \
+        else return az_fail("unknown game id");                       \
     } while (0)
+
+static std::atomic<unsigned long long> g_fused_attr_done{0};        // bit d = k_c4_move_fused may use its LDS on device d
 
 extern "C" {
 
 const char* az_last_error(void) { return g_err.c_str(); }
 int az_version(void) { return 1; }
 
+static int engine_alloc(az_engine* e) {
+    Dev& d = e->d;
+    const size_t pool_bytes = (size_t)d.G * d.cap * (e->A + 1) * sizeof(uint4);
+    hipError_t err;
+    if ((err = hipMalloc(&d.pool, pool_bytes)) != hipSuccess ||
+        (err = hipMalloc(&d.slots, (size_t)d.G * sizeof(Slot))) != hipSuccess ||
+        (err = hipMalloc(&d.rec_visits, (size_t)d.G * AZ_MAX_MOVES * AZ_MAX_ACTIONS * 4)) != hipSuccess ||
+        (err = hipMalloc(&d.ring, (size_t)d.ring_cap * sizeof(az_game_record))) != hipSuccess ||
+        (err = hipMalloc(&d.ring_count, 256)) != hipSuccess)
+        return az_fail("hipMalloc (node pools)", err);
+    HIPCHK(hipMemset(d.slots, 0, (size_t)d.G * sizeof(Slot)));
+    HIPCHK(hipMemset(d.rec_visits, 0, (size_t)d.G * AZ_MAX_MOVES * AZ_MAX_ACTIONS * 4));
+    HIPCHK(hipMemset(d.ring_count, 0, 256));
+    int rc = az_reset_games(e, nullptr);
+    if (rc) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    return 0;
+}
+
 int az_engine_create(const az_engine_config* cfg, az_engine** out) {
-    if (!cfg || !out) return fail("null argument");
-    if (cfg->game != AZ_GAME_C4 && cfg->game != AZ_GAME_TTT) return fail("unknown game id");
-    if (cfg->num_games <= 0) return fail("num_games must be positive");
-    if (cfg->num_simulations < 0) return fail("num_simulations must be >= 0");
-    HIPCHK(hipSetDevice(cfg->device));
-    az_engine* e = new az_engine();
-    e->cfg = *cfg;
-    e->A = cfg->game == AZ_GAME_C4 ? GameC4::A : GameTTT::A;
+    if (!cfg || !out) return az_fail("null argument");
+    *out = nullptr;
+    if (cfg->game != AZ_GAME_C4 && cfg->game != AZ_GAME_TTT) return az_fail("unknown game id");
+    if (cfg->num_games <= 0) return az_fail("num_games must be positive");
+    if (cfg->num_simulations < 0) return az_fail("num_simulations must be >= 0");
     const int lmax = cfg->game == AZ_GAME_C4 ? GameC4::LMAX : GameTTT::LMAX;
     long cap = cfg->node_capacity;
     if (cap <= 0) cap = cfg->reuse_search_tree ? (long)cfg->num_simulations * lmax + lmax + 1
                                                : (long)cfg->num_simulations + 2;
-    if (cap >= (1l << 28)) { delete e; return fail("node_capacity too large"); }
+    if (cap >= (1l << 28)) return az_fail("node_capacity too large");
+    DeviceScope scope(cfg->device);
+    if (scope.err != hipSuccess) return az_fail("selecting the engine's device", scope.err);
+    int cus = 0;
+    HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device));
+    if (cus <= 0) return az_fail("device reports no compute units");
+    az_engine* e = new az_engine();
+    e->cfg = *cfg;
+    e->A = cfg->game == AZ_GAME_C4 ? GameC4::A : GameTTT::A;
+    e->num_cus = cus;
+    e->err_flags = 0;
     Dev& d = e->d;
     memset(&d, 0, sizeof(d));
     d.G = cfg->num_games; d.cap = (int)cap; d.S = cfg->num_simulations;
@@ -1101,29 +1173,20 @@ int az_engine_create(const az_engine_config* cfg, az_engine** out) {
     d.seed = cfg->seed; d.first_uid = cfg->first_game_uid;
     d.uid_stride = cfg->uid_stride ? cfg->uid_stride : (uint64_t)cfg->num_games;
     d.ring_cap = 2u * (uint32_t)cfg->num_games + 16u;
-    const size_t pool_bytes = (size_t)d.G * d.cap * (e->A + 1) * sizeof(uint4);
-    hipError_t err;
-    if ((err = hipMalloc(&d.pool, pool_bytes)) != hipSuccess ||
-        (err = hipMalloc(&d.slots, (size_t)d.G * sizeof(Slot))) != hipSuccess ||
-        (err = hipMalloc(&d.rec_visits, (size_t)d.G * AZ_MAX_MOVES * AZ_MAX_ACTIONS * 4)) != hipSuccess ||
-        (err = hipMalloc(&d.ring, (size_t)d.ring_cap * sizeof(az_game_record))) != hipSuccess ||
-        (err = hipMalloc(&d.ring_count, 256)) != hipSuccess) {
+    const int rc = engine_alloc(e);
+    if (rc) {                         // nothing is handed out half-built: free what was allocated
+        const std::string why = g_err;
         az_engine_destroy(e);
-        return fail("hipMalloc (node pools)", err);
+        g_err = why;
+        return rc;
     }
-    HIPCHK(hipMemset(d.slots, 0, (size_t)d.G * sizeof(Slot)));
-    HIPCHK(hipMemset(d.rec_visits, 0, (size_t)d.G * AZ_MAX_MOVES * AZ_MAX_ACTIONS * 4));
-    HIPCHK(hipMemset(d.ring_count, 0, 256));
     *out = e;
-    int rc = az_reset_games(e, nullptr);
-    if (rc) return rc;
-    HIPCHK(hipDeviceSynchronize());
     return 0;
 }
 
 int az_engine_destroy(az_engine* e) {
     if (!e) return 0;
-    (void)hipSetDevice(e->cfg.device);
+    DeviceScope scope(e->cfg.device);
     (void)hipFree(e->d.pool); (void)hipFree(e->d.slots); (void)hipFree(e->d.rec_visits); (void)hipFree(e->d.ring);
     (void)hipFree(e->d.ring_count); (void)hipFree(e->lut_dev); (void)hipFree(e->d.cache); (void)hipFree(e->d.cache_hits);
     delete e;
@@ -1131,16 +1194,19 @@ int az_engine_destroy(az_engine* e) {
 }
 
 int az_reset_games(az_engine* e, void* stream) {
-    if (!e) return fail("null engine");
+    if (!e) return az_fail("null engine");
+    ENGINE_SCOPE(e);
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipMemsetAsync(e->d.ring_count, 0, 256, st));
+    e->err_flags = 0;
     DISPATCH_GAME(e->cfg.game, hipLaunchKernelGGL((k_reset<GM>), wave_grid(e->d.G), dim3(BLOCK_THREADS), 0, st, e->d));
     LAUNCH_CHECK();
     return 0;
 }
 
 int az_set_puct_lut(az_engine* e, const double* lut_host, int32_t n) {
-    if (!e || !lut_host || n <= 0) return fail("bad PUCT table");
+    if (!e || !lut_host || n <= 0) return az_fail("bad PUCT table");
+    ENGINE_SCOPE(e);
     double2* dev = nullptr;
     HIPCHK(hipMalloc(&dev, (size_t)n * sizeof(double2)));
     HIPCHK(hipMemcpy(dev, lut_host, (size_t)n * sizeof(double2), hipMemcpyHostToDevice));
@@ -1151,7 +1217,7 @@ int az_set_puct_lut(az_engine* e, const double* lut_host, int32_t n) {
 }
 
 int az_set_model_version(az_engine* e, int32_t version) {
-    if (!e) return fail("null engine");
+    if (!e) return az_fail("null engine");
     e->d.version = version; e->cfg.model_version = version;
     return 0;
 }
@@ -1161,9 +1227,9 @@ int az_set_model_version(az_engine* e, int32_t version) {
 static size_t cache_counters(int G) { return (size_t)8 * G + 8; }
 
 int az_eval_cache_enable(az_engine* e, int32_t log2_entries) {
-    if (!e) return fail("null engine");
-    if (log2_entries != 0 && (log2_entries < 10 || log2_entries > 28)) return fail("eval cache: log2_entries must be 0 or 10..28");
-    HIPCHK(hipSetDevice(e->cfg.device));
+    if (!e) return az_fail("null engine");
+    ENGINE_SCOPE(e);
+    if (log2_entries != 0 && (log2_entries < 10 || log2_entries > 28)) return az_fail("eval cache: log2_entries must be 0 or 10..28");
     HIPCHK(hipDeviceSynchronize());
     (void)hipFree(e->d.cache); (void)hipFree(e->d.cache_hits);
     e->d.cache = nullptr; e->d.cache_mask = 0; e->d.cache_hits = nullptr;
@@ -1174,7 +1240,7 @@ int az_eval_cache_enable(az_engine* e, int32_t log2_entries) {
     unsigned long long* c = nullptr;
     hipError_t err = hipMalloc(&t, bytes);
     if (err == hipSuccess) err = hipMalloc(&c, counters * 8);
-    if (err != hipSuccess) { (void)hipFree(t); return fail("hipMalloc (evaluation cache)", err); }
+    if (err != hipSuccess) { (void)hipFree(t); return az_fail("hipMalloc (evaluation cache)", err); }
     HIPCHK(hipMemset(t, 0, bytes));
     HIPCHK(hipMemset(c, 0, counters * 8));
     HIPCHK(hipDeviceSynchronize());
@@ -1183,7 +1249,8 @@ int az_eval_cache_enable(az_engine* e, int32_t log2_entries) {
 }
 
 int az_eval_cache_hits(az_engine* e, uint64_t* hits, void* stream) {
-    if (!e || !hits) return fail("null argument");
+    if (!e || !hits) return az_fail("null argument");
+    ENGINE_SCOPE(e);
     *hits = 0;
     if (!e->d.cache_hits) return 0;
     std::vector<unsigned long long> h(cache_counters(e->d.G));
@@ -1194,7 +1261,8 @@ int az_eval_cache_hits(az_engine* e, uint64_t* hits, void* stream) {
 }
 
 int az_begin_move(az_engine* e, uint64_t* leaf_bb, int32_t* leaf_info, void* stream) {
-    if (!e || !leaf_bb || !leaf_info) return fail("null argument");
+    if (!e || !leaf_bb || !leaf_info) return az_fail("null argument");
+    ENGINE_SCOPE(e);
     DISPATCH_GAME(e->cfg.game, hipLaunchKernelGGL((k_begin_move<GM, false>), wave_grid(e->d.G), dim3(BLOCK_THREADS), 0,
                                                   (hipStream_t)stream, e->d, leaf_bb, leaf_info, (const double*)nullptr));
     LAUNCH_CHECK();
@@ -1202,7 +1270,8 @@ int az_begin_move(az_engine* e, uint64_t* leaf_bb, int32_t* leaf_info, void* str
 }
 
 int az_begin_move_uniform(az_engine* e, const double* eta, void* stream) {
-    if (!e) return fail("null engine");
+    if (!e) return az_fail("null engine");
+    ENGINE_SCOPE(e);
     DISPATCH_GAME(e->cfg.game, hipLaunchKernelGGL((k_begin_move<GM, true>), wave_grid(e->d.G), dim3(BLOCK_THREADS), 0,
                                                   (hipStream_t)stream, e->d, (uint64_t*)nullptr, (int32_t*)nullptr, eta));
     LAUNCH_CHECK();
@@ -1210,7 +1279,8 @@ int az_begin_move_uniform(az_engine* e, const double* eta, void* stream) {
 }
 
 int az_apply_root(az_engine* e, const float* p, const double* eta, void* stream) {
-    if (!e || !p) return fail("null argument");
+    if (!e || !p) return az_fail("null argument");
+    ENGINE_SCOPE(e);
     DISPATCH_GAME(e->cfg.game, hipLaunchKernelGGL((k_apply_root<GM>), wave_grid(e->d.G), dim3(BLOCK_THREADS), 0,
                                                   (hipStream_t)stream, e->d, p, eta));
     LAUNCH_CHECK();
@@ -1218,7 +1288,8 @@ int az_apply_root(az_engine* e, const float* p, const double* eta, void* stream)
 }
 
 int az_select(az_engine* e, uint64_t* leaf_bb, int32_t* leaf_info, void* stream) {
-    if (!e || !leaf_bb || !leaf_info) return fail("null argument");
+    if (!e || !leaf_bb || !leaf_info) return az_fail("null argument");
+    ENGINE_SCOPE(e);
     DISPATCH_GAME(e->cfg.game, { const int gs_ = group_size_for(GroupSize<GM>::min_value, e->d.G); const dim3 gr_ = group_grid(e->d.G, gs_);
   switch (gs_) {
     case 8: if constexpr (8 >= GroupSize<GM>::min_value) hipLaunchKernelGGL((k_sim_step_p<GM, 8, false, true>), gr_, dim3(BLOCK_THREADS), 0, (hipStream_t)stream, e->d, (const float*)nullptr, (const float*)nullptr, leaf_bb, leaf_info); break;
@@ -1231,7 +1302,8 @@ int az_select(az_engine* e, uint64_t* leaf_bb, int32_t* leaf_info, void* stream)
 }
 
 int az_expand_backup(az_engine* e, const float* p, const float* v, void* stream) {
-    if (!e || !p || !v) return fail("null argument");
+    if (!e || !p || !v) return az_fail("null argument");
+    ENGINE_SCOPE(e);
     DISPATCH_GAME(e->cfg.game, { const int gs_ = group_size_for(GroupSize<GM>::min_value, e->d.G); const dim3 gr_ = group_grid(e->d.G, gs_);
   switch (gs_) {
     case 8: if constexpr (8 >= GroupSize<GM>::min_value) hipLaunchKernelGGL((k_sim_step_p<GM, 8, true, false>), gr_, dim3(BLOCK_THREADS), 0, (hipStream_t)stream, e->d, p, v, (uint64_t*)nullptr, (int32_t*)nullptr); break;
@@ -1244,9 +1316,10 @@ int az_expand_backup(az_engine* e, const float* p, const float* v, void* stream)
 }
 
 int az_sim_step(az_engine* e, float* p, float* v, uint64_t* leaf_bb, int32_t* leaf_info, void* stream) {
-    if (!e || !leaf_bb || !leaf_info) return fail("null argument");
+    if (!e || !leaf_bb || !leaf_info) return az_fail("null argument");
+    ENGINE_SCOPE(e);
     if (!p) return az_select(e, leaf_bb, leaf_info, stream);
-    if (!v) return fail("v is required with p");
+    if (!v) return az_fail("v is required with p");
     DISPATCH_GAME(e->cfg.game, { const int gs_ = group_size_for(GroupSize<GM>::min_value, e->d.G); const dim3 gr_ = group_grid(e->d.G, gs_);
   switch (gs_) {
     case 8: if constexpr (8 >= GroupSize<GM>::min_value) hipLaunchKernelGGL((k_sim_step_p<GM, 8, true, true>), gr_, dim3(BLOCK_THREADS), 0, (hipStream_t)stream, e->d, p, v, leaf_bb, leaf_info); break;
@@ -1267,33 +1340,35 @@ int az_debug_counters(az_engine* e, unsigned long long* out4) {
 }
 #endif
 
-int az_c4_move_fused(az_engine* e, const uint8_t* blob, int32_t num_blocks, uint64_t* leaf_bb, int32_t* leaf_info,
-                     float* p, float* v, void* stream) {
-    if (!e || !blob || !leaf_bb || !leaf_info || !p || !v) return fail("null argument");
-    if (e->cfg.game != AZ_GAME_C4) return fail("az_c4_move_fused: Connect Four only");
-    if (num_blocks < 0) return fail("az_c4_move_fused: num_blocks");
+// games per workgroup of the one-launch-per-move kernel: spread over one workgroup per compute unit, at most
+// 64 (eight search lanes per game, 512 threads)
+#define FUSED_MAX_GPW 64
+static int fused_launch(az_engine* e, const uint8_t* blob, int32_t num_blocks, uint64_t* leaf_bb, int32_t* leaf_info,
+                        float* p, float* v, hipStream_t st) {
+    if (e->cfg.game != AZ_GAME_C4) return az_fail("az_c4_move_fused: Connect Four only");
+    if (num_blocks < 0) return az_fail("az_c4_move_fused: num_blocks");
     if (e->d.S <= 0) return 0;
-    // games per workgroup: spread over one workgroup per CU, at most 64 (eight search lanes per game)
-    const int cus = 256;
-    const int gpw = (e->d.G + cus - 1) / cus;
-    if (gpw > 64) return fail("az_c4_move_fused: at most 16384 games");
+    const int gpw = (e->d.G + e->num_cus - 1) / e->num_cus;
+    if (gpw > FUSED_MAX_GPW) return az_fail("az_c4_move_fused: more than 64 games per compute unit");
     const int grid = (e->d.G + gpw - 1) / gpw;
-    static unsigned long long attr_done = 0;         // bit d = dynamic-LDS attribute set on device d
-    int dev_id = 0;
-    HIPCHK(hipGetDevice(&dev_id));
-    if (dev_id >= 64 || !((attr_done >> dev_id) & 1ull)) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_c4_move_fused),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        if (dev_id < 64) attr_done |= 1ull << dev_id;
-    }
-    hipLaunchKernelGGL(k_c4_move_fused, dim3(grid), dim3(NTHREADS), LDS_BYTES, (hipStream_t)stream, e->d, blob,
-                       (int)num_blocks, leaf_bb, leaf_info, p, v, (int)e->d.S, gpw);
-    LAUNCH_CHECK();
+    // already done by az_engine_create on this device (a bitmap test, then nothing)
+    if (int rc = az_set_kernel_lds(reinterpret_cast<const void*>(k_c4_move_fused), LDS_BYTES, g_fused_attr_done)) return rc;
+    hipLaunchKernelGGL(k_c4_move_fused, dim3(grid), dim3(NTHREADS), LDS_BYTES, st, e->d, blob, (int)num_blocks, leaf_bb,
+                       leaf_info, p, v, (int)e->d.S, gpw);
+    AZ_LAUNCH_CHECK("k_c4_move_fused");
     return 0;
 }
 
+int az_c4_move_fused(az_engine* e, const uint8_t* blob, int32_t num_blocks, uint64_t* leaf_bb, int32_t* leaf_info,
+                     float* p, float* v, void* stream) {
+    if (!e || !blob || !leaf_bb || !leaf_info || !p || !v) return az_fail("null argument");
+    ENGINE_SCOPE(e);
+    return fused_launch(e, blob, num_blocks, leaf_bb, leaf_info, p, v, (hipStream_t)stream);
+}
+
 int az_run_sims_uniform(az_engine* e, int32_t num_sims, void* stream) {
-    if (!e || num_sims < 0) return fail("bad argument");
+    if (!e || num_sims < 0) return az_fail("bad argument");
+    ENGINE_SCOPE(e);
     DISPATCH_GAME(e->cfg.game, { const int gs_ = group_size_for(GroupSize<GM>::min_value, e->d.G); const dim3 gr_ = group_grid(e->d.G, gs_);
   switch (gs_) {
     case 8: if constexpr (8 >= GroupSize<GM>::min_value) hipLaunchKernelGGL((k_run_uniform_p<GM, 8>), gr_, dim3(BLOCK_THREADS), 0, (hipStream_t)stream, e->d, (int)num_sims); break;
@@ -1307,7 +1382,8 @@ int az_run_sims_uniform(az_engine* e, int32_t num_sims, void* stream) {
 
 int az_choose_and_advance(az_engine* e, const double* u, int32_t* action, int32_t* num_edges, uint32_t* visits,
                           int32_t* winner, void* stream) {
-    if (!e) return fail("null engine");
+    if (!e) return az_fail("null engine");
+    ENGINE_SCOPE(e);
     DISPATCH_GAME(e->cfg.game, hipLaunchKernelGGL((k_choose<GM>), wave_grid(e->d.G), dim3(BLOCK_THREADS), 0,
                                                   (hipStream_t)stream, e->d, u, action, num_edges, visits, winner));
     LAUNCH_CHECK();
@@ -1315,14 +1391,17 @@ int az_choose_and_advance(az_engine* e, const double* u, int32_t* action, int32_
 }
 
 int az_drain_finished(az_engine* e, az_game_record* out_host, int32_t max_records, int32_t* num_out, void* stream) {
-    if (!e || !num_out) return fail("null argument");
+    if (!e || !num_out) return az_fail("null argument");
+    ENGINE_SCOPE(e);
     hipStream_t st = (hipStream_t)stream;
-    uint32_t count = 0;
-    HIPCHK(hipMemcpyAsync(&count, e->d.ring_count, 4, hipMemcpyDeviceToHost, st));
+    uint32_t head[2] = {0, 0};               // {records in the ring, error bits}
+    HIPCHK(hipMemcpyAsync(head, e->d.ring_count, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    uint32_t count = head[0];
+    e->err_flags |= head[1];
     if (count > e->d.ring_cap) count = e->d.ring_cap;
-    if ((int32_t)count > max_records) return fail("az_drain_finished: output buffer too small");
-    if (count && !out_host) return fail("null output buffer");
+    if ((int32_t)count > max_records) return az_fail("az_drain_finished: output buffer too small");
+    if (count && !out_host) return az_fail("null output buffer");
     if (count) HIPCHK(hipMemcpyAsync(out_host, e->d.ring, (size_t)count * sizeof(az_game_record), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemsetAsync(e->d.ring_count, 0, 4, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -1330,8 +1409,22 @@ int az_drain_finished(az_engine* e, az_game_record* out_host, int32_t max_record
     return 0;
 }
 
+int az_take_finished_device(az_engine* e, az_game_record* out_dev, int32_t max_records, int32_t* head_dev, void* stream) {
+    if (!e || !out_dev || !head_dev || max_records < 0) return az_fail("bad argument");
+    ENGINE_SCOPE(e);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_take_finished, dim3(256), dim3(256), 0, st, e->d.ring, e->d.ring_count, e->d.ring_cap, out_dev,
+                       (uint32_t)max_records, head_dev);
+    AZ_LAUNCH_CHECK("k_take_finished");
+    HIPCHK(hipMemsetAsync(e->d.ring_count, 0, 4, st));
+    return 0;
+}
+
+int az_engine_error_flags(const az_engine* e) { return e ? (int)e->err_flags : -1; }
+
 int az_get_stats(az_engine* e, az_stats* out, void* stream) {
-    if (!e || !out) return fail("null argument");
+    if (!e || !out) return az_fail("null argument");
+    ENGINE_SCOPE(e);
     hipStream_t st = (hipStream_t)stream;
     std::vector<Slot> h((size_t)e->d.G);
     HIPCHK(hipMemcpyAsync(h.data(), e->d.slots, h.size() * sizeof(Slot), hipMemcpyDeviceToHost, st));
@@ -1349,9 +1442,10 @@ int az_node_words(const az_engine* e) { return e ? 4 * (e->A + 1) : 0; }
 
 int az_set_position(az_engine* e, int32_t g, uint64_t bb_next, uint64_t bb_prev, int32_t num_moves,
                     const uint32_t* nodes_host, int32_t num_nodes, uint32_t root_node) {
-    if (!e || g < 0 || g >= e->d.G) return fail("bad game slot");
-    if (num_nodes < 0 || num_nodes > e->d.cap) return fail("tree larger than node_capacity");
-    if (root_node != AZ_NO_NODE && root_node >= (uint32_t)num_nodes) return fail("root_node out of range");
+    if (!e || g < 0 || g >= e->d.G) return az_fail("bad game slot");
+    ENGINE_SCOPE(e);
+    if (num_nodes < 0 || num_nodes > e->d.cap) return az_fail("tree larger than node_capacity");
+    if (root_node != AZ_NO_NODE && root_node >= (uint32_t)num_nodes) return az_fail("root_node out of range");
     HIPCHK(hipDeviceSynchronize());
     Slot s;
     HIPCHK(hipMemcpy(&s, e->d.slots + g, sizeof(Slot), hipMemcpyDeviceToHost));
@@ -1360,15 +1454,15 @@ int az_set_position(az_engine* e, int32_t g, uint64_t bb_next, uint64_t bb_prev,
     HIPCHK(hipMemcpy(e->d.slots + g, &s, sizeof(Slot), hipMemcpyHostToDevice));
     const size_t node_bytes = (size_t)(e->A + 1) * sizeof(uint4);
     if (num_nodes) {
-        if (!nodes_host) return fail("null node image");
+        if (!nodes_host) return az_fail("null node image");
         // child indices must stay inside the image
         const int words = 4 * (e->A + 1);
         for (int n = 0; n < num_nodes; ++n) {
             const uint32_t ne = nodes_host[(size_t)n * words + 4 * e->A];
-            if (ne > (uint32_t)e->A) return fail("node image: num_edges out of range");
+            if (ne > (uint32_t)e->A) return az_fail("node image: num_edges out of range");
             for (uint32_t i = 0; i < ne; ++i) {
                 const uint32_t c = nodes_host[(size_t)n * words + 4 * i + 3];
-                if (c != AZ_NO_NODE && c >= (uint32_t)num_nodes) return fail("node image: child out of range");
+                if (c != AZ_NO_NODE && c >= (uint32_t)num_nodes) return az_fail("node image: child out of range");
             }
         }
         HIPCHK(hipMemcpy((char*)e->d.pool + (size_t)g * e->d.cap * node_bytes, nodes_host, (size_t)num_nodes * node_bytes,
@@ -1379,13 +1473,14 @@ int az_set_position(az_engine* e, int32_t g, uint64_t bb_next, uint64_t bb_prev,
 
 int az_get_tree(az_engine* e, int32_t g, uint32_t* nodes_host, int32_t max_nodes, int32_t* num_nodes,
                 uint32_t* root_node) {
-    if (!e || g < 0 || g >= e->d.G || !num_nodes || !root_node) return fail("bad argument");
+    if (!e || g < 0 || g >= e->d.G || !num_nodes || !root_node) return az_fail("bad argument");
+    ENGINE_SCOPE(e);
     HIPCHK(hipDeviceSynchronize());
     Slot s;
     HIPCHK(hipMemcpy(&s, e->d.slots + g, sizeof(Slot), hipMemcpyDeviceToHost));
     *num_nodes = (int32_t)s.alloc; *root_node = s.root;
     if (!nodes_host) return 0;
-    if ((int32_t)s.alloc > max_nodes) return fail("az_get_tree: buffer too small");
+    if ((int32_t)s.alloc > max_nodes) return az_fail("az_get_tree: buffer too small");
     const size_t node_bytes = (size_t)(e->A + 1) * sizeof(uint4);
     if (s.alloc)
         HIPCHK(hipMemcpy(nodes_host, (char*)e->d.pool + (size_t)g * e->d.cap * node_bytes, (size_t)s.alloc * node_bytes,
@@ -1396,7 +1491,7 @@ int az_get_tree(az_engine* e, int32_t g, uint32_t* nodes_host, int32_t max_nodes
 // ---- stateless bulk kernels -------------------------------------------------
 int az_positions_from_history(int32_t game, const uint8_t* hist, const int32_t* len, int32_t stride, int32_t n,
                               uint64_t* bb, int32_t* num_moves, void* stream) {
-    if (n < 0 || (n && (!hist || !len || !bb || !num_moves))) return fail("bad argument");
+    if (n < 0 || (n && (!hist || !len || !bb || !num_moves))) return az_fail("bad argument");
     if (n == 0) return 0;
     DISPATCH_GAME(game, hipLaunchKernelGGL((k_from_history<GM>), dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                                            hist, len, (int)stride, (int)n, bb, num_moves));
@@ -1406,7 +1501,7 @@ int az_positions_from_history(int32_t game, const uint8_t* hist, const int32_t* 
 
 int az_game_query(int32_t game, const uint64_t* bb, const int32_t* num_moves, int32_t n, int32_t* legal_mask,
                   int32_t* terminal, int32_t* winner, void* stream) {
-    if (n < 0 || (n && (!bb || !num_moves))) return fail("bad argument");
+    if (n < 0 || (n && (!bb || !num_moves))) return az_fail("bad argument");
     if (n == 0) return 0;
     DISPATCH_GAME(game, hipLaunchKernelGGL((k_query<GM>), dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, bb,
                                            num_moves, (int)n, legal_mask, terminal, winner));
@@ -1416,7 +1511,7 @@ int az_game_query(int32_t game, const uint64_t* bb, const int32_t* num_moves, in
 
 int az_game_step(int32_t game, uint64_t* bb, int32_t* num_moves, const int32_t* action, int32_t n, int32_t* status,
                  void* stream) {
-    if (n < 0 || (n && (!bb || !num_moves || !action))) return fail("bad argument");
+    if (n < 0 || (n && (!bb || !num_moves || !action))) return az_fail("bad argument");
     if (n == 0) return 0;
     DISPATCH_GAME(game, hipLaunchKernelGGL((k_step<GM>), dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, bb,
                                            num_moves, action, (int)n, status));
@@ -1425,7 +1520,7 @@ int az_game_step(int32_t game, uint64_t* bb, int32_t* num_moves, const int32_t* 
 }
 
 int az_render(int32_t game, const uint64_t* bb, int32_t n, float* x, uint8_t* valid, void* stream) {
-    if (n < 0 || (n && !bb)) return fail("bad argument");
+    if (n < 0 || (n && !bb)) return az_fail("bad argument");
     if (n == 0) return 0;
     DISPATCH_GAME(game, {
         const long total = (long)n * 2 * GM::H * GM::W;
@@ -1439,7 +1534,7 @@ int az_render(int32_t game, const uint64_t* bb, int32_t n, float* x, uint8_t* va
 int az_examples_from_records(int32_t game, const az_game_record* records, int32_t n, const int32_t* state_offset,
                              int32_t total, float* x, float* p, float* z, uint8_t* valid, int32_t* version,
                              void* stream) {
-    if (n < 0 || total < 0 || (total && (!records || !state_offset || !x || !p || !z || !valid))) return fail("bad argument");
+    if (n < 0 || total < 0 || (total && (!records || !state_offset || !x || !p || !z || !valid))) return az_fail("bad argument");
     if (total == 0) return 0;
     DISPATCH_GAME(game, hipLaunchKernelGGL((k_examples<GM>), dim3((total + 127) / 128), dim3(128), 0, (hipStream_t)stream,
                                            records, (int)n, state_offset, (int)total, x, p, z, valid, version));
@@ -1448,7 +1543,7 @@ int az_examples_from_records(int32_t game, const az_game_record* records, int32_
 }
 
 int az_masked_softmax(int32_t game, const float* logits, const int32_t* leaf_info, int32_t n, float* p, void* stream) {
-    if (n < 0 || (n && (!logits || !leaf_info || !p))) return fail("bad argument");
+    if (n < 0 || (n && (!logits || !leaf_info || !p))) return az_fail("bad argument");
     if (n == 0) return 0;
     DISPATCH_GAME(game, hipLaunchKernelGGL((k_masked_softmax<GM::A>), dim3((n + 255) / 256), dim3(256), 0,
                                            (hipStream_t)stream, logits, leaf_info, (int)n, p));
@@ -1458,7 +1553,8 @@ int az_masked_softmax(int32_t game, const float* logits, const int32_t* leaf_inf
 
 int az_ucb_score(az_engine* e, const uint32_t* N, const float* W, const float* P, const int32_t* num_edges, int32_t n,
                  double* score, int32_t* argmax, void* stream) {
-    if (!e || n < 0 || (n && (!N || !W || !P || !num_edges || !score || !argmax))) return fail("bad argument");
+    if (!e || n < 0 || (n && (!N || !W || !P || !num_edges || !score || !argmax))) return az_fail("bad argument");
+    ENGINE_SCOPE(e);
     if (n == 0) return 0;
     DISPATCH_GAME(e->cfg.game, hipLaunchKernelGGL((k_ucb<GM::A>), dim3((n + 255) / 256), dim3(256), 0,
                                                   (hipStream_t)stream, e->d, N, W, P, num_edges, (int)n, score, argmax));

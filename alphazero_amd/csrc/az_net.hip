@@ -26,6 +26,7 @@
 // A 3x3 tap is therefore a constant byte offset folded into the ds_read instruction; the
 // 8th column is computed like a cell and its result is stored to a dump row instead.
 #include "az_net_dev.h"
+#include "az_host.h"
 
 __global__ void __launch_bounds__(NTHREADS, 2)
 k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* __restrict__ leaf_bb,
@@ -178,28 +179,23 @@ int az_c4net_blob_bytes(void) { return BLOB_BYTES; }
 
 int az_c4net_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uint64_t* leaf_bb,
                           const int32_t* leaf_info, int32_t n, float* p, float* v, void* stream) {
-    if (n < 0 || num_blocks < 0 || (n && (!blob || !leaf_bb || !p || !v))) return -1;
+    if (n < 0 || num_blocks < 0 || (n && (!blob || !leaf_bb || !p || !v)))
+        return az_fail("az_c4net_bf16_forward: null pointer or negative count");
     if (n == 0) return 0;
-    // the large dynamic LDS size is a per-device attribute of the kernel: set once per device
-    static unsigned long long attr_done = 0;         // bit d = done on device d
-    int dev_id = 0;
-    if (hipGetDevice(&dev_id) != hipSuccess) return -2;
-    if (dev_id >= 64 || !((attr_done >> dev_id) & 1ull)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_c4net_bf16), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                LDS_BYTES) != hipSuccess)
-            return -2;
-        if (dev_id < 64) attr_done |= 1ull << dev_id;
-    }
+    // MAXIT wave-tasks per wave, 64 leaves per scanning thread
+    if (n > 32768) return az_fail("az_c4net_bf16_forward: at most 32768 leaves per call");
+    static std::atomic<unsigned long long> attr_done{0};
+    if (int rc = az_set_kernel_lds(reinterpret_cast<const void*>(k_c4net_bf16), LDS_BYTES, attr_done)) return rc;
     // one persistent workgroup per CU at most; a power of two so slots map to waves by bit masks; with
     // fewer leaves than wave slots they are spread over the CUs first (slot s = WG s % grid)
     const int ntasks = (n + 1) / 2;
     int grid_shift = 0;
     while ((1 << grid_shift) < ntasks && grid_shift < 8) ++grid_shift;
     const int grid = 1 << grid_shift;
-    if (n > 32768) return -4;                    // MAXIT wave-tasks per wave, 64 leaves per scanning thread
     hipLaunchKernelGGL(k_c4net_bf16, dim3(grid), dim3(NTHREADS), LDS_BYTES, (hipStream_t)stream, blob, (int)num_blocks,
                        leaf_bb, leaf_info, (int)n, p, v, grid_shift);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
+    AZ_LAUNCH_CHECK("k_c4net_bf16");
+    return 0;
 }
 
 }  // extern "C"

@@ -16,6 +16,7 @@
 #include <stdint.h>
 
 #include "../../include/azhip.h"
+#include "az_host.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -467,24 +468,18 @@ long az_c4net128_workspace_bytes(int32_t n) { return n < 0 ? -1 : (long)(act_byt
 
 int az_c4net128_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uint64_t* leaf_bb,
                              const int32_t* leaf_info, int32_t n, void* workspace, float* p, float* v, void* stream) {
-    if (n < 0 || num_blocks < 0 || (n && (!blob || !leaf_bb || !workspace || !p || !v))) return -1;
+    if (n < 0 || num_blocks < 0 || (n && (!blob || !leaf_bb || !workspace || !p || !v)))
+        return az_fail("az_c4net128_bf16_forward: null pointer or negative count");
     if (n == 0) return 0;
-    if (leaf_info && n > 32768) return -4;              // k_compact128 keeps 32 flags per thread
+    // k_compact128 keeps 32 flags per thread
+    if (leaf_info && n > 32768) return az_fail("az_c4net128_bf16_forward: at most 32768 leaves per call with leaf_info");
     hipStream_t st = (hipStream_t)stream;
     __bf16* t0 = reinterpret_cast<__bf16*>(workspace);
     int32_t* list = leaf_info ? reinterpret_cast<int32_t*>(static_cast<uint8_t*>(workspace) + act_bytes(n)) : nullptr;
     if (list) hipLaunchKernelGGL(k_compact128, dim3(1), dim3(1024), 0, st, leaf_info, (int)n, list);
     const int lds = BIAS_OFF + 2 * CH * 4;
-    // the large dynamic LDS size is a per-device attribute of the kernel: set once per device
-    static unsigned long long attr_done = 0;         // bit d = done on device d
-    int dev_id = 0;
-    if (hipGetDevice(&dev_id) != hipSuccess) return -2;
-    if (dev_id >= 64 || !((attr_done >> dev_id) & 1ull)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower128), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                lds) != hipSuccess)
-            return -2;
-        if (dev_id < 64) attr_done |= 1ull << dev_id;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    if (int rc = az_set_kernel_lds(reinterpret_cast<const void*>(k_tower128), lds, attr_done)) return rc;
     const int ngroups = (n + GB - 1) / GB;
     const long stem_threads = (long)act_positions(n) * 8;
     // grids cover all n leaves; workgroups past the compacted count leave at once
@@ -496,7 +491,8 @@ int az_c4net128_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uint
                            (const int32_t*)list, (int)n);
     hipLaunchKernelGGL(k_heads128, dim3((n + HB_ - 1) / HB_), dim3(256), 0, st, blob, t0, leaf_bb, (const int32_t*)list,
                        (int)n, p, v);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
+    AZ_LAUNCH_CHECK("k_stem128 / k_tower128 / k_heads128");
+    return 0;
 }
 
 }  // extern "C"

@@ -16,6 +16,7 @@
 #include <stdint.h>
 
 #include "../../include/azhip.h"
+#include "az_host.h"
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -201,22 +202,16 @@ int az_c4net_f32_blob_floats(void) { return F_BLOB_FLOATS; }
 
 int az_c4net_f32_forward(const float* blob, int32_t num_blocks, const uint64_t* leaf_bb, int32_t n, float* p,
                          float* v, void* stream) {
-    if (n < 0 || num_blocks < 0 || (n && (!blob || !leaf_bb || !p || !v))) return -1;
+    if (n < 0 || num_blocks < 0 || (n && (!blob || !leaf_bb || !p || !v)))
+        return az_fail("az_c4net_f32_forward: null pointer or negative count");
     if (n == 0) return 0;
     const int lds = (2 * FACT_FLOATS + 288 * 32 + 128) * 4;
-    // the large dynamic LDS size is a per-device attribute of the kernel: set once per device
-    static unsigned long long attr_done = 0;         // bit d = done on device d
-    int dev_id = 0;
-    if (hipGetDevice(&dev_id) != hipSuccess) return -2;
-    if (dev_id >= 64 || !((attr_done >> dev_id) & 1ull)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_c4net_f32), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                lds) != hipSuccess)
-            return -2;
-        if (dev_id < 64) attr_done |= 1ull << dev_id;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    if (int rc = az_set_kernel_lds(reinterpret_cast<const void*>(k_c4net_f32), lds, attr_done)) return rc;
     hipLaunchKernelGGL(k_c4net_f32, dim3((n + FB - 1) / FB), dim3(FTHREADS), lds, (hipStream_t)stream, blob,
                        (int)num_blocks, leaf_bb, (int)n, p, v);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
+    AZ_LAUNCH_CHECK("k_c4net_f32");
+    return 0;
 }
 
 }  // extern "C"

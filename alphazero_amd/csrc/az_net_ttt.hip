@@ -9,6 +9,7 @@
 #include <stdint.h>
 
 #include "../../include/azhip.h"
+#include "az_host.h"
 
 namespace {
 
@@ -206,22 +207,15 @@ int launch(const float* blob, int num_blocks, const uint64_t* leaf_bb, const int
            float* v, hipStream_t st) {
     using Lc = L<C>;
     const int lds = (((Lc::TOTAL + 3) & ~3) + TT_WAVES * 2 * Lc::BPW * Lc::STRIP) * (int)sizeof(float);
-    // dynamic LDS beyond 64 KB is a per-device attribute of the kernel: set once per device
-    static unsigned long long attr_done = 0;         // bit d = done on device d
-    int dev_id = 0;
-    if (hipGetDevice(&dev_id) != hipSuccess) return -2;
-    if (dev_id >= 64 || !((attr_done >> dev_id) & 1ull)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tttnet_f32<C>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return -2;
-        if (dev_id < 64) attr_done |= 1ull << dev_id;
-    }
+    static std::atomic<unsigned long long> attr_done{0};      // one bitmap per channel width
+    if (int rc = az_set_kernel_lds(reinterpret_cast<const void*>(k_tttnet_f32<C>), lds, attr_done)) return rc;
     const int tasks = (n + Lc::BPW - 1) / Lc::BPW;
     int grid = (tasks + TT_WAVES - 1) / TT_WAVES;
     if (grid > 1024) grid = 1024;
     hipLaunchKernelGGL((k_tttnet_f32<C>), dim3(grid), dim3(TT_THREADS), lds, st, blob, num_blocks, leaf_bb, leaf_info,
                        n, p, v);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
+    AZ_LAUNCH_CHECK("k_tttnet_f32");
+    return 0;
 }
 
 }  // namespace
@@ -239,14 +233,15 @@ int az_tttnet_f32_blob_floats(int32_t channels) {
 
 int az_tttnet_f32_forward(const float* blob, int32_t channels, int32_t num_blocks, const uint64_t* leaf_bb,
                           const int32_t* leaf_info, int32_t n, float* p, float* v, void* stream) {
-    if (n < 0 || num_blocks < 0 || (n && (!blob || !leaf_bb || !p || !v))) return -1;
+    if (n < 0 || num_blocks < 0 || (n && (!blob || !leaf_bb || !p || !v)))
+        return az_fail("az_tttnet_f32_forward: null pointer or negative count");
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     switch (channels) {
         case 4: return launch<4>(blob, num_blocks, leaf_bb, leaf_info, n, p, v, st);
         case 8: return launch<8>(blob, num_blocks, leaf_bb, leaf_info, n, p, v, st);
         case 16: return launch<16>(blob, num_blocks, leaf_bb, leaf_info, n, p, v, st);
-        default: return -1;                      // channels must be 4, 8 or 16
+        default: return az_fail("az_tttnet_f32_forward: channels must be 4, 8 or 16");
     }
 }
 

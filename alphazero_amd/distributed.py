@@ -2,8 +2,11 @@
 gloo in CPU tests).  Games shard across ranks with no data-path collective; these replace
 the reference's Redis model server and SQLite sink between processes:
 
-  broadcast_model  <-  ModelServer.update / latest   (alphazero/model_server.py:19-40)
-  gather_records   <-  ReplayBufferDataset.add_game   (alphazero/replay_buffer.py:165-167)
+  broadcast_model / broadcast_packed     <-  ModelServer.update / latest   (alphazero/model_server.py:19-40)
+  gather_records / gather_records_device <-  ReplayBufferDataset.add_game   (alphazero/replay_buffer.py:165-167)
+
+The *_packed / *_device forms are the ones the self-play loop uses: weights travel in kernel-ready form
+and records never leave device memory; the others move torch modules and host-side record lists.
 """
 import ctypes as C
 
@@ -47,6 +50,57 @@ def broadcast_model(model, version, src=0, group=None):
             t.copy_(flat[off:off + n].view(t.dtype).view(t.shape))
             off += n
     return version
+
+
+def broadcast_packed(net, version, src=0, group=None):
+    """New weights for the <= 32-channel HIP network in kernel-ready form: ONE in-place broadcast of
+    `net.wire` (FusedC4Net: 256-byte header {version, num_blocks} + packed blob, ~80 KB) from `src`.
+    The publishing rank packs once (FusedC4Net.load_module); receivers evaluate straight from the
+    buffer the collective wrote -- no state_dict, no re-packing, no copies.  Returns the version on
+    every rank (one 16-byte host read).  Replaces ModelServer.update / latest
+    (alphazero/model_server.py:19-40) between self-play ranks."""
+    hdr = net.wire[:16].view(torch.int64)
+    if dist.get_rank(group) == src:
+        hdr.copy_(torch.tensor([int(version), int(net.num_blocks)], dtype=torch.int64))
+    dist.broadcast(net.wire, src, group=group)
+    version, blocks = hdr.tolist()
+    net.num_blocks = int(blocks)
+    return int(version)
+
+
+def gather_records_device(records, head, dst=0, group=None):
+    """Finished games of every rank collected on `dst` without leaving device memory:
+    (records, head) as returned by SelfPlayEngine.take_finished_device on each rank ->
+    (uint8 tensor [sum n, RECORD_BYTES] on `dst` in rank order -- an empty tensor elsewhere --, OR of
+    the ranks' error bits).  One all_gather of the 8-byte heads, whose host read is the only
+    synchronisation, then one gather of the records padded to the largest count.  Replaces
+    ReplayBufferDataset.add_game across processes (alphazero/replay_buffer.py:165-167, 28-47)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    home = records.device
+    if records.is_cuda and dist.get_backend(group) == 'gloo':
+        # gloo has no device gather: CPU-only rehearsals of the multi-rank path stage through the host
+        head = head.cpu()
+    heads = [torch.empty_like(head) for _ in range(world)]
+    dist.all_gather(heads, head, group=group)
+    hs = torch.stack(heads).tolist()                     # one host read for all counts
+    counts = [h[0] for h in hs]
+    flags = 0
+    for h in hs:
+        flags |= h[1]
+    cap = max(counts)
+    empty = records[:0]
+    if cap == 0:
+        return empty, flags
+    send = records[:cap]
+    if send.device != head.device:
+        send = send.to(head.device)
+    if rank == dst:
+        bufs = [torch.empty_like(send) for _ in range(world)]
+        dist.gather(send, bufs, dst=dst, group=group)
+        return torch.cat([bufs[r][:counts[r]] for r in range(world)]).to(home), flags
+    dist.gather(send, None, dst=dst, group=group)
+    return empty, flags
 
 
 def records_to_bytes(records):

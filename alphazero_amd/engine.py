@@ -26,8 +26,9 @@ def make_puct_lut(n, c_base=19652, c_init=1.25):
     return np.ascontiguousarray(np.stack([cs, np.sqrt(ns)], axis=1), dtype=np.float64)
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(device=None):
+    """torch's current stream on `device` (default: the current device) as the void* the C ABI takes."""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 class SelfPlayEngine:
@@ -61,7 +62,11 @@ class SelfPlayEngine:
             self.out_visits = torch.zeros(self.G, self.A, dtype=torch.int32, device=self.device)
             self.out_winner = torch.zeros(self.G, dtype=torch.int32, device=self.device)
         self._drain_buf = None
+        self._take_buf = None
         self._pv = None
+
+    def _stream(self):
+        return _stream(self.device)
 
     def close(self):
         if getattr(self, 'h', None):
@@ -84,7 +89,7 @@ class SelfPlayEngine:
         check(self.lib.az_set_model_version(self.h, int(v)))
 
     def reset_games(self):
-        check(self.lib.az_reset_games(self.h, _stream()))
+        check(self.lib.az_reset_games(self.h, self._stream()))
 
     def enable_eval_cache(self, log2_entries):
         """Device table of 2**log2_entries evaluator outputs keyed by (position, model version); 0
@@ -95,27 +100,27 @@ class SelfPlayEngine:
 
     def eval_cache_hits(self):
         n = C.c_uint64()
-        check(self.lib.az_eval_cache_hits(self.h, C.byref(n), _stream()))
+        check(self.lib.az_eval_cache_hits(self.h, C.byref(n), self._stream()))
         return int(n.value)
 
     # ---- one move, lock-step ---------------------------------------------------
     def begin_move(self):
-        check(self.lib.az_begin_move(self.h, ptr(self.leaf_bb), ptr(self.leaf_info), _stream()))
+        check(self.lib.az_begin_move(self.h, ptr(self.leaf_bb), ptr(self.leaf_info), self._stream()))
         return self.leaf_bb, self.leaf_info
 
     def apply_root(self, p, eta=None):
         assert p.dtype == torch.float32 and p.is_contiguous() and p.shape == (self.G, self.A)
         if eta is not None:
             assert eta.dtype == torch.float64 and eta.is_contiguous() and eta.shape == (self.G, self.A)
-        check(self.lib.az_apply_root(self.h, ptr(p), ptr(eta), _stream()))
+        check(self.lib.az_apply_root(self.h, ptr(p), ptr(eta), self._stream()))
 
     def begin_move_uniform(self, eta=None):
         if eta is not None:
             assert eta.dtype == torch.float64 and eta.is_contiguous() and eta.shape == (self.G, self.A)
-        check(self.lib.az_begin_move_uniform(self.h, ptr(eta), _stream()))
+        check(self.lib.az_begin_move_uniform(self.h, ptr(eta), self._stream()))
 
     def select(self):
-        check(self.lib.az_select(self.h, ptr(self.leaf_bb), ptr(self.leaf_info), _stream()))
+        check(self.lib.az_select(self.h, ptr(self.leaf_bb), ptr(self.leaf_info), self._stream()))
         return self.leaf_bb, self.leaf_info
 
     def _check_pv(self, p, v):
@@ -124,12 +129,12 @@ class SelfPlayEngine:
 
     def expand_backup(self, p, v):
         self._check_pv(p, v)
-        check(self.lib.az_expand_backup(self.h, ptr(p), ptr(v), _stream()))
+        check(self.lib.az_expand_backup(self.h, ptr(p), ptr(v), self._stream()))
 
     def sim_step(self, p=None, v=None):
         if p is not None:
             self._check_pv(p, v)
-        check(self.lib.az_sim_step(self.h, ptr(p), ptr(v), ptr(self.leaf_bb), ptr(self.leaf_info), _stream()))
+        check(self.lib.az_sim_step(self.h, ptr(p), ptr(v), ptr(self.leaf_bb), ptr(self.leaf_info), self._stream()))
         return self.leaf_bb, self.leaf_info
 
     def move_fused(self, net):
@@ -139,16 +144,16 @@ class SelfPlayEngine:
                         torch.zeros(self.G, dtype=torch.float32, device=self.device))
         p, v = self._pv
         check(self.lib.az_c4_move_fused(self.h, ptr(net.blob), int(net.num_blocks), ptr(self.leaf_bb),
-                                        ptr(self.leaf_info), ptr(p), ptr(v), _stream()))
+                                        ptr(self.leaf_info), ptr(p), ptr(v), self._stream()))
 
     def run_sims_uniform(self, num_sims):
-        check(self.lib.az_run_sims_uniform(self.h, int(num_sims), _stream()))
+        check(self.lib.az_run_sims_uniform(self.h, int(num_sims), self._stream()))
 
     def choose_and_advance(self, u=None):
         if u is not None:
             assert u.dtype == torch.float64 and u.is_contiguous() and u.numel() == self.G
         check(self.lib.az_choose_and_advance(self.h, ptr(u), ptr(self.out_action), ptr(self.out_nedges),
-                                             ptr(self.out_visits), ptr(self.out_winner), _stream()))
+                                             ptr(self.out_visits), ptr(self.out_winner), self._stream()))
         return self.out_action, self.out_nedges, self.out_visits, self.out_winner
 
     # ---- results -----------------------------------------------------------------
@@ -161,17 +166,34 @@ class SelfPlayEngine:
             self._drain_buf = torch.empty(cap * C.sizeof(GameRecord), dtype=torch.uint8).pin_memory()
         n = C.c_int32()
         check(self.lib.az_drain_finished(self.h, C.cast(self._drain_buf.data_ptr(), C.POINTER(GameRecord)), cap,
-                                         C.byref(n), _stream()))
+                                         C.byref(n), self._stream()))
         return self._drain_buf.numpy()[:n.value * C.sizeof(GameRecord)].reshape(n.value, C.sizeof(GameRecord))
+
+    def take_finished_device(self):
+        """Finished games since the last hand-over, left on the device: (records uint8 [ring capacity,
+        sizeof(az_game_record)], head int32[2] = {number of valid records, error bits}), both tensors of
+        this engine that the next call overwrites.  No host synchronisation."""
+        cap = 2 * self.G + 16
+        if self._take_buf is None:
+            self._take_buf = (torch.zeros(cap, C.sizeof(GameRecord), dtype=torch.uint8, device=self.device),
+                              torch.zeros(2, dtype=torch.int32, device=self.device))
+        recs, head = self._take_buf
+        check(self.lib.az_take_finished_device(self.h, ptr(recs), cap, ptr(head), self._stream()))
+        return recs, head
 
     def drain_finished(self):
         """Finished games since the last drain as a list of GameRecord (synchronises)."""
         raw = self.drain_finished_bytes()
         return [GameRecord.from_buffer_copy(raw[i].tobytes()) for i in range(raw.shape[0])]
 
+    def error_flags(self):
+        """Error bits seen by the drains since the last reset: 1 = a node pool ran out, 2 = finished
+        games were dropped because the record ring was full.  No device work."""
+        return int(self.lib.az_engine_error_flags(self.h))
+
     def stats(self):
         st = Stats()
-        check(self.lib.az_get_stats(self.h, C.byref(st), _stream()))
+        check(self.lib.az_get_stats(self.h, C.byref(st), self._stream()))
         return {k: int(getattr(st, k)) for k, _ in Stats._fields_}
 
     # ---- tree transfer (single-game mirror) -------------------------------------------

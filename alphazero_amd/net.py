@@ -16,6 +16,24 @@ from ._lib import check, ptr
 CMAX = 32          # trunk channels supported by the fused kernel
 
 
+def _device(d):
+    """torch.device with an explicit ordinal ('cuda' means the device current at construction)."""
+    d = torch.device(d)
+    if d.type == 'cuda' and d.index is None:
+        d = torch.device('cuda', torch.cuda.current_device())
+    return d
+
+
+def _launch(device, fn):
+    """Call fn(stream) with `device` current: the network entry points launch on the current device,
+    so an evaluator built for cuda:1 must not run on whatever device the caller happens to have selected."""
+    st = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    if torch.cuda.current_device() == device.index:
+        return check(fn(st))
+    with torch.cuda.device(device):
+        return check(fn(st))
+
+
 def _fold_bn(w, bn, conv_bias=None):
     """Eval-mode BN folded into the preceding conv: returns (w * s[co], shift[co]) in float64."""
     s = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
@@ -113,12 +131,22 @@ def pack_c4_blob(model):
     return blob
 
 
+WIRE_HEADER = 256      # bytes in front of the packed weights in FusedC4Net.wire: int64 {model version, num_blocks}
+
+
 class FusedC4Net:
+    """Evaluator over the packed weights.  `wire` is the one buffer that travels between ranks when new
+    weights are published (distributed.broadcast_packed): a 256-byte header and the kernel-ready blob, so a
+    receiving rank uses the weights where they land, without re-packing."""
+
     def __init__(self, blob, num_blocks, device):
         self.lib = _lib.load()
-        self.device = torch.device(device)
+        self.device = _device(device)
         self.num_blocks = int(num_blocks)
-        self.blob = blob.to(self.device).contiguous()
+        self.wire = torch.zeros(WIRE_HEADER + blob.numel(), dtype=torch.uint8, device=self.device)
+        self.blob = self.wire[WIRE_HEADER:]
+        self.blob.copy_(blob)
+        assert self.blob.data_ptr() % 16 == 0
         self._p = self._v = None
 
     @classmethod
@@ -136,8 +164,7 @@ class FusedC4Net:
         if self._p is None or self._p.shape[0] != n:
             self._p = torch.empty(n, 7, dtype=torch.float32, device=self.device)
             self._v = torch.empty(n, dtype=torch.float32, device=self.device)
-        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        check(self.lib.az_c4net_bf16_forward(ptr(self.blob), self.num_blocks, ptr(leaf_bb), ptr(leaf_info),
+        _launch(self.device, lambda st: self.lib.az_c4net_bf16_forward(ptr(self.blob), self.num_blocks, ptr(leaf_bb), ptr(leaf_info),
                                              n, ptr(self._p), ptr(self._v), st))
         return self._p, self._v
 
@@ -186,7 +213,7 @@ class FusedC4NetF32:
 
     def __init__(self, model, device=None):
         self.lib = _lib.load()
-        self.device = torch.device(device if device is not None else next(model.parameters()).device)
+        self.device = _device(device if device is not None else next(model.parameters()).device)
         self.num_blocks = model.num_blocks
         self.blob = pack_c4_blob_f32(model).to(self.device)
         self._p = self._v = None
@@ -199,8 +226,7 @@ class FusedC4NetF32:
         if self._p is None or self._p.shape[0] != n:
             self._p = torch.empty(n, 7, dtype=torch.float32, device=self.device)
             self._v = torch.empty(n, dtype=torch.float32, device=self.device)
-        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        check(self.lib.az_c4net_f32_forward(ptr(self.blob), self.num_blocks, ptr(leaf_bb), n,
+        _launch(self.device, lambda st: self.lib.az_c4net_f32_forward(ptr(self.blob), self.num_blocks, ptr(leaf_bb), n,
                                             ptr(self._p), ptr(self._v), st))
         return self._p, self._v
 
@@ -241,7 +267,7 @@ class C4Net128:
 
     def __init__(self, model, device=None, max_leaves=16384):
         self.lib = _lib.load()
-        self.device = torch.device(device if device is not None else next(model.parameters()).device)
+        self.device = _device(device if device is not None else next(model.parameters()).device)
         self.num_blocks = model.num_blocks
         self.blob = pack_c4_blob_128(model).to(self.device)
         self.max_leaves = max_leaves
@@ -258,8 +284,7 @@ class C4Net128:
         if self._p is None or self._p.shape[0] != n:
             self._p = torch.empty(n, 7, dtype=torch.float32, device=self.device)
             self._v = torch.empty(n, dtype=torch.float32, device=self.device)
-        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        check(self.lib.az_c4net128_bf16_forward(ptr(self.blob), self.num_blocks, ptr(leaf_bb), ptr(leaf_info), n,
+        _launch(self.device, lambda st: self.lib.az_c4net128_bf16_forward(ptr(self.blob), self.num_blocks, ptr(leaf_bb), ptr(leaf_info), n,
                                                 ptr(self.workspace), ptr(self._p), ptr(self._v), st))
         return self._p, self._v
 
@@ -314,7 +339,7 @@ class TTTNetF32:
 
     def __init__(self, model, device=None):
         self.lib = _lib.load()
-        self.device = torch.device(device if device is not None else next(model.parameters()).device)
+        self.device = _device(device if device is not None else next(model.parameters()).device)
         self.num_blocks, self.channels = model.num_blocks, model.block_channels
         self.blob = pack_ttt_blob_f32(model).to(self.device)
         self._p = self._v = None
@@ -332,7 +357,6 @@ class TTTNetF32:
         if self._p is None or self._p.shape[0] != n:
             self._p = torch.zeros(n, 9, dtype=torch.float32, device=self.device)
             self._v = torch.zeros(n, dtype=torch.float32, device=self.device)
-        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        check(self.lib.az_tttnet_f32_forward(ptr(self.blob), self.channels, self.num_blocks, ptr(leaf_bb),
+        _launch(self.device, lambda st: self.lib.az_tttnet_f32_forward(ptr(self.blob), self.channels, self.num_blocks, ptr(leaf_bb),
                                              ptr(leaf_info), n, ptr(self._p), ptr(self._v), st))
         return self._p, self._v

@@ -286,27 +286,35 @@ class DeviceReplayWindow:
 
     def add_records(self, raw):
         """raw: uint8 [n, sizeof(az_game_record)] (numpy array or CPU tensor).  Returns the number of states added."""
-        torch, C = self._torch, self._C
         raw = np.ascontiguousarray(np.asarray(raw, dtype=np.uint8)).reshape(-1, self.record_bytes)
-        n = raw.shape[0]
+        if raw.shape[0] == 0:
+            return 0
+        return self.add_records_device(self._torch.from_numpy(raw).to(self.device))
+
+    def add_records_device(self, recs):
+        """recs: uint8 tensor [n, sizeof(az_game_record)] already on the window's device (as
+        SelfPlayEngine.take_finished_device / distributed.gather_records_device deliver them): the
+        records never visit the host; the only host read is the total number of states."""
+        torch, C = self._torch, self._C
+        recs = recs.reshape(-1, self.record_bytes).contiguous()
+        n = recs.shape[0]
         if n == 0:
             return 0
         off_moves = self._lib.GameRecord.num_moves.offset
-        moves = raw[:, off_moves:off_moves + 4].copy().view(np.int32).reshape(n)
-        offsets = np.zeros(n + 1, np.int32)
-        np.cumsum(moves, out=offsets[1:])
-        total = int(offsets[-1])
-        recs = torch.from_numpy(raw).to(self.device)
-        offs = torch.from_numpy(offsets).to(self.device)
+        moves = recs[:, off_moves:off_moves + 4].contiguous().view(torch.int32).reshape(n)
+        offs = torch.zeros(n + 1, dtype=torch.int32, device=self.device)
+        offs[1:] = torch.cumsum(moves, 0)
+        total = int(offs[-1].item())
         x = torch.empty((total,) + self.shape, dtype=torch.float32, device=self.device)
         p = torch.empty(total, self.A, dtype=torch.float32, device=self.device)
         z = torch.empty(total, dtype=torch.float32, device=self.device)
         valid = torch.empty(total, self.A, dtype=torch.uint8, device=self.device)
         version = torch.empty(total, dtype=torch.int32, device=self.device)
         ptr = self._lib.ptr
-        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        self._lib.check(self.lib.az_examples_from_records(self.game_id, ptr(recs), n, ptr(offs), total, ptr(x), ptr(p),
-                                                          ptr(z), ptr(valid), ptr(version), st))
+        with torch.cuda.device(self.device):
+            st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            self._lib.check(self.lib.az_examples_from_records(self.game_id, ptr(recs), n, ptr(offs), total, ptr(x), ptr(p),
+                                                              ptr(z), ptr(valid), ptr(version), st))
         keep = min(total, self.capacity)                         # a batch larger than the window keeps its tail
         src = slice(total - keep, total)
         dst = (torch.arange(self.count + total - keep, self.count + total, device=self.device) % self.capacity)

@@ -9,6 +9,16 @@ the reference's train.py (`while version < num_steps: worker.play_game()`) work 
 they are.  Collaborators are duck-typed exactly as in the reference:
 `model_server.latest(model) -> int`, `dataset.add_game(game, version)`,
 `config.Game()`, `config.Model()`, `config.selfplay[...]`.
+
+Where this differs from the reference, because game slots outlive a call:
+  * a game can span several model versions (weights are refreshed once per `play_game()` /
+    `play_moves()` call, games finish whenever they finish), and with `reuse_search_tree` its tree keeps
+    the priors and values of the weights that expanded each node -- including the uniform prior of
+    version 0 across the switch to the first real weights.  The reference plays a whole game with one
+    version (selfplay.py:18,41).  `dataset.add_game(game, v)` gets the version current when the game
+    ENDED; the record also carries the version current when it STARTED (`first_model_version`).
+  * pool exhaustion and record-ring overflow cannot happen in the reference; here `collect_finished*`
+    raises AzError as soon as the engine reports either.
 """
 import numpy as np
 import torch
@@ -29,6 +39,13 @@ def record_to_game(game_cls, rec):
 class SelfPlayWorker:
     def __init__(self, config, model_server, dataset, device, num_games=1024, seed=0,
                  rank=0, world_size=1, evaluator=None, eval_cache_log2=0):
+        if evaluator is not None and eval_cache_log2:
+            # az_sim_step answers cached leaves by writing rows of the (p, v) buffers it is given; a
+            # caller's evaluator may return fresh tensors or leave other rows undefined, which would feed
+            # garbage into expand/backup without any error.  The built-in HIP networks own persistent
+            # buffers and touch only the rows they evaluate, so the cache is theirs alone.
+            raise ValueError('eval_cache_log2 works with the built-in HIP networks only, not with a '
+                             'caller-supplied evaluator')
         self._config = config
         self._model_server = model_server
         self._dataset = dataset
@@ -64,13 +81,15 @@ class SelfPlayWorker:
             # leaves whose position was already evaluated under the current model version are answered
             # by the engine; sound only for evaluators that are pure, batch-independent functions of
             # the position, which the HIP networks are and a torch module in general is not
-            if self._fused is None and evaluator is None:
-                raise ValueError('eval_cache_log2 needs one of the HIP networks (or a caller-supplied evaluator)')
+            if self._fused is None:
+                raise ValueError('eval_cache_log2 needs one of the built-in HIP networks')
             self.engine.enable_eval_cache(eval_cache_log2)
         # Connect Four with the <= 32-channel network: a whole move's simulations run in one launch
         # (az_c4_move_fused)
         from .net import FusedC4Net as _F
         self._fused_move = isinstance(self._fused, _F) and evaluator is None and self.num_games <= 16384
+        if self._fused is not None and not self._fused_move and self.num_games > 32768:
+            raise ValueError('the HIP network kernels take at most 32768 leaves per call: num_games <= 32768')
         self._version = 0
         self.positions = 0
         self.games_finished = 0
@@ -105,8 +124,16 @@ class SelfPlayWorker:
         eng.choose_and_advance()
         self.positions += self.num_games
 
+    def _check_engine(self):
+        flags = self.engine.error_flags()
+        if flags:
+            raise _engine.AzError(
+                ('a game ran out of node-pool space (raise node_capacity); ' if flags & 1 else '') +
+                ('finished games were dropped, the record ring was full (collect more often)' if flags & 2 else ''))
+
     def collect_finished(self):
         recs = self.engine.drain_finished()
+        self._check_engine()
         for r in recs:
             self._dataset.add_game(record_to_game(self._game_cls, r), int(r.model_version))
         self.games_finished += len(recs)
@@ -116,8 +143,20 @@ class SelfPlayWorker:
         """Finished games as raw az_game_record bytes (uint8 [n, record size]); `dataset` is not
         touched.  For loops that feed a DeviceReplayWindow or ship records to another rank."""
         raw = self.engine.drain_finished_bytes().copy()
+        self._check_engine()
         self.games_finished += raw.shape[0]
         return raw
+
+    def collect_finished_device(self):
+        """Finished games left on the device: uint8 tensor [n, record size] (a copy the caller owns);
+        one 8-byte host read for the count and the error bits."""
+        recs, head = self.engine.take_finished_device()
+        n, flags = head.tolist()
+        self.engine_flags = flags
+        if flags:
+            raise _engine.AzError(f'engine error bits {flags}: 1 = node pool exhausted, 2 = finished games dropped')
+        self.games_finished += n
+        return recs[:n].clone()
 
     def refresh_model(self):
         """selfplay.py:16-22: pull the latest weights; version 0 means 'no model yet'."""

@@ -2,8 +2,9 @@
 (alphazero/train.py:85-95), for one GPU or one process per GPU:
 
     every rank : SelfPlayWorker plays lock-step moves for its shard of the games
-    records    : raw az_game_record bytes, gathered on the trainer rank (RCCL) -- replaces the SQLite file
-    trainer    : DeviceReplayWindow.add_records -> TrainingWorker.process_batch (one SGD step)
+    records    : raw az_game_record bytes, device to device: engine ring -> gather on the trainer rank (RCCL)
+                 -> DeviceReplayWindow, never through host memory -- replaces the SQLite file
+    trainer    : DeviceReplayWindow.add_records_device -> TrainingWorker.process_batch (one SGD step)
     weights    : ModelServer.update on the trainer rank, ModelServer.sync (one broadcast) everywhere
 
 With data_parallel=True every rank trains instead: records are all-gathered, every rank keeps the same
@@ -56,12 +57,23 @@ def synchronous_play_and_train(config, device, num_games=1024, num_steps=None, m
         uniform = worker._version <= 0
         for _ in range(moves_per_step):
             worker.play_move(uniform)
-        raw = worker.collect_finished_bytes()
-        if multi:
+        if multi and data_parallel:
+            # every rank keeps the whole window: records of all ranks on all ranks
             from .distributed import gather_record_bytes
-            raw = gather_record_bytes(raw, dst=None if data_parallel else trainer_rank, device=device)
-        if trainer is not None:
+            raw = gather_record_bytes(worker.collect_finished_bytes(), dst=None, device=device)
             window.add_records(raw)
+        elif multi:
+            # records stay in device memory from the engine's ring to the trainer's window
+            from .distributed import gather_records_device
+            recs, head = worker.engine.take_finished_device()
+            recs, flags = gather_records_device(recs, head, dst=trainer_rank)
+            if flags:
+                raise RuntimeError(f'engine error bits {flags} on some rank')
+            if trainer is not None:
+                window.add_records_device(recs)
+        else:
+            window.add_records_device(worker.collect_finished_device())
+        if trainer is not None:
             version = trainer.process_batch() or version          # 0 while the window is still too small
             if log and rank == trainer_rank:
                 log(f'version {version}: {len(window)} states in the window, {window.num_games} games')

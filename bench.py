@@ -11,10 +11,18 @@ are random-initialised (throughput does not depend on their values).
   python bench.py --gpus N --steps K --warmup W [--model uniform|c4_6x32|c4_10x128]
                   [--games G] [--sims S] [--no-cpu-baseline]
 
-Launched by torch.distributed.run for N > 1 (one rank per GPU, RCCL); games shard across
-ranks with no data-path collective (scaling: weak); per step the weights are broadcast from
-rank 0 (when a network is in use) and the finished games' records are gathered on rank 0.
-Rank 0 prints one JSON line.
+N > 1: one rank per GPU over RCCL.  Either torch.distributed.run launches the ranks (RANK /
+WORLD_SIZE / MASTER_* in the environment), or -- `python bench.py --gpus N` on its own -- this
+script starts them itself as child processes before it touches a GPU and relays rank 0's line
+(replaces the reference's mp.spawn of self-play workers, alphazero/train.py:131-134).  Games
+shard across ranks with no data-path collective (scaling: weak); per step the packed weights are
+broadcast from rank 0 (when a network is in use) and the finished games' records are gathered
+on rank 0, both device to device.  Rank 0 prints one JSON line.
+
+At N = 1 the line also carries, measured after the timed region: `fp32_net` (the same loop with
+the fp32 parity network kernel), `agreement` (bf16 production path against the fp32 kernel in
+the loop on identical random streams), `config4_leaf_eval` (the 10x128 network on 16 384-leaf
+batches) and `cpu_baseline`.
 """
 import argparse
 import json
@@ -113,6 +121,158 @@ def _cpu_worker(model_name, sims, seconds, wid):
     return pos, sim, time.time() - t0
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this same command as children
+    of torch.distributed.run (one per GPU, rendezvous on 127.0.0.1) and relay what rank 0 prints.
+    Runs before anything in this process has touched a GPU; the parent never does."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.call(cmd, env=env)
+
+
+def physical_cores():
+    """(logical CPUs, physical cores) of the host as the kernel reports them."""
+    cores = set()
+    try:
+        phys = core = None
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('physical id'):
+                phys = line.split(':')[1].strip()
+            elif line.startswith('core id'):
+                core = line.split(':')[1].strip()
+            elif not line.strip():
+                if core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+        if core is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    return os.cpu_count() or 1, len(cores) or None
+
+
+def cpu_share():
+    """CPUs this job may use: the affinity mask, further limited by OMP_NUM_THREADS when the host sets it
+    (a one-GPU slice of a shared machine sees every CPU of the machine but owns only its share)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        n = min(n, int(os.environ['OMP_NUM_THREADS']))
+    except (KeyError, ValueError):
+        pass
+    return max(n, 1)
+
+
+def latest_profile(name_suffix):
+    """Newest committed profiles/rNN_<suffix> (the rounds' files sort by name)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r[0-9][0-9]_{name_suffix}')))
+    return files[-1] if files else None
+
+
+def measure_agreement(dev, net_bf16, net_f32, S, games=256, moves=12, seed=77):
+    """The production path (bf16 network, one launch per move) against the fp32 parity kernel in the
+    stepwise loop (alphazero/mcts.py:94-107 evaluates in fp32), `games` Connect Four games from the empty
+    board on identical Dirichlet / sampling streams (same engine seed: the device RNG is a function of
+    seed, game and move).  A (game, move) pair is compared while the two runs have played the same
+    moves so far."""
+    import numpy as np
+    import torch
+    from alphazero_amd import engine as E
+    engs = [E.SelfPlayEngine(E._lib.GAME_C4, games, S, exploration_depth=4, reuse_search_tree=True,
+                             alpha=0.3, epsilon=0.25, seed=seed, device=dev.index) for _ in range(2)]
+    same = np.ones(games, bool)
+    compared = equal_moves = equal_visits = 0
+    l1_sum, l1_max = 0.0, 0.0
+    for mv in range(moves):
+        out = []
+        for k, eng in enumerate(engs):
+            net = net_bf16 if k == 0 else net_f32
+            bb, info = eng.begin_move()
+            p, _ = net(bb, info)
+            eng.apply_root(p)
+            if k == 0:
+                eng.move_fused(net)
+            else:
+                bb, info = eng.select()
+                for s_ in range(S):
+                    p, v = net(bb, info)
+                    if s_ < S - 1:
+                        bb, info = eng.sim_step(p, v)
+                    else:
+                        eng.expand_backup(p, v)
+            a, ne, vis, w = eng.choose_and_advance()
+            out.append((a.cpu().numpy().copy(), vis.cpu().numpy().astype(np.float64)))
+        (a0, v0), (a1, v1) = out
+        live = same & (a0 >= 0) & (a1 >= 0)
+        if live.any():
+            pi0 = v0[live] / np.maximum(v0[live].sum(1, keepdims=True), 1)
+            pi1 = v1[live] / np.maximum(v1[live].sum(1, keepdims=True), 1)
+            l1 = np.abs(pi0 - pi1).sum(1)
+            compared += int(live.sum())
+            equal_moves += int((a0[live] == a1[live]).sum())
+            equal_visits += int((v0[live] == v1[live]).all(1).sum())
+            l1_sum += float(l1.sum())
+            l1_max = max(l1_max, float(l1.max()))
+        same &= a0 == a1
+    for eng in engs:
+        eng.close()
+    return {'games': games, 'sims_per_move': S, 'moves_per_game': moves, 'positions_compared': compared,
+            'moves_equal_frac': equal_moves / max(compared, 1),
+            'visit_vectors_identical_frac': equal_visits / max(compared, 1),
+            'mean_l1_pi': l1_sum / max(compared, 1), 'max_l1_pi': l1_max,
+            'games_identical_to_the_end': int(same.sum()),
+            'note': 'bf16 MFMA network in az_c4_move_fused vs az_c4net_f32_forward in the stepwise loop; same '
+                    'noise and sampling streams; pairs compared while both runs share the history'}
+
+
+def config4_leaf_eval(dev, iters=10, n=16384):
+    """BASELINE config 4: the 10x128 Connect Four network on batches of 16 384 random legal positions
+    (uniform random playouts of depth U[0,30]), bf16 MFMA; time per batch from HIP events."""
+    import numpy as np
+    import torch
+    from alphazero_amd import engine as E
+    from alphazero_amd.models import AlphaZeroC4
+    from alphazero_amd.net import C4Net128
+    from alphazero_amd.games.connectfour import ConnectFour
+    rng = np.random.RandomState(0)
+    hists = []
+    while len(hists) < 2048:                      # 2 048 distinct playouts, repeated to fill the batch
+        g, depth = ConnectFour(), rng.randint(0, 31)
+        while len(g) < depth and not g.terminal:
+            g.take_action(int(rng.choice(g.valid_actions)))
+        if not g.terminal:
+            hists.append(list(g.history))
+    bb, _ = E.positions_from_history(E._lib.GAME_C4, [hists[i % len(hists)] for i in range(n)], device=dev)
+    torch.manual_seed(0)
+    model = AlphaZeroC4(10, 128).to(dev).eval()
+    net = C4Net128(model, dev, max_leaves=n)
+    for _ in range(3):
+        net(bb)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in ev:
+        a.record()
+        net(bb)
+        b.record()
+    torch.cuda.synchronize()
+    ms = sum(a.elapsed_time(b) for a, b in ev) / iters
+    fl = trunk_flops_per_leaf(10, 128) * n
+    tf = fl / (ms * 1e-3) / 1e12
+    return {'workload': f'AlphaZeroC4 10x128 forward, {n} random legal positions per batch', 'ms_per_batch': ms,
+            'leaves_per_s': n / (ms * 1e-3), 'kernel': 'k_stem128 + k_tower128 + k_heads128', 'bound': 'mfma',
+            'achieved': tf, 'peak': BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / BF16_PEAK_TFLOPS,
+            'flops_per_leaf': trunk_flops_per_leaf(10, 128), 'dtype': 'bf16 MFMA, f32 accumulate'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -141,12 +301,17 @@ def main():
                          'default for the <= 32-channel HIP network up to 16384 games')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--no-extras', action='store_true',
+                    help='skip the untimed extra measurements of the N = 1 line (fp32 network, agreement, 10x128 batches)')
     args = ap.parse_args()
+
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
     from alphazero_amd import engine as E
-    from alphazero_amd.distributed import gather_record_bytes
+    from alphazero_amd.distributed import broadcast_packed, gather_records_device
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -156,6 +321,8 @@ def main():
     rehearse = os.environ.get('AZ_BENCH_REHEARSE') == '1'
     if rehearse:
         local = 0
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit(f'bench.py: --gpus {args.gpus} but the launcher started {world} ranks')
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local)
@@ -180,7 +347,6 @@ def main():
         blocks, ch = (6, 32) if args.model == 'c4_6x32' else (10, 128)
         torch.manual_seed(0)
         net = AlphaZeroC4(blocks, ch).to(dev).eval()
-        from alphazero_amd.distributed import broadcast_model
         if args.net_impl == 'hip':
             from alphazero_amd.net import C4Net128, FusedC4Net
             fused = FusedC4Net.from_module(net, dev) if ch <= 32 else C4Net128(net, dev, max_leaves=G)
@@ -195,6 +361,8 @@ def main():
     if use_cache:
         eng.enable_eval_cache(args.eval_cache_log2)
     step_no = [0]
+    finished_on_dst = [0]
+    packed_wire = net is not None and args.net_impl == 'hip' and args.model == 'c4_6x32'
     net_ev, tree_ev, move_ev = [], [], []       # (start, end) HIP event pairs on the launch stream
 
     def timed(fn, sink, on):
@@ -212,9 +380,15 @@ def main():
             eng.begin_move_uniform()
             timed(lambda: eng.run_sims_uniform(S), tree_ev, measure)
         else:
-            if world > 1:
-                # RCCL weight broadcast replaces model_server.latest() (model_server.py:32-40);
-                # the fused kernel's packed weights are rebuilt from the received tensors
+            if world > 1 and packed_wire:
+                # RCCL weight broadcast replaces model_server.latest() (model_server.py:32-40): the
+                # publishing rank packs its module once, the kernel-ready buffer travels, receivers
+                # evaluate from where it lands
+                if rank == 0:
+                    fused.load_module(net)
+                broadcast_packed(fused, step_no[0] + 1, src=0)
+            elif world > 1:
+                from alphazero_amd.distributed import broadcast_model
                 broadcast_model(net, 1, src=0)
                 if args.net_impl == 'hip':
                     fused.load_module(net)
@@ -228,9 +402,7 @@ def main():
                 timed(lambda: eng.move_fused(fused), move_ev, measure)
                 eng.choose_and_advance()
                 if measure:
-                    raw = eng.drain_finished_bytes()
-                    if world > 1:
-                        gather_record_bytes(raw, dst=0, device='cpu' if rehearse else dev)
+                    hand_over()
                 return
             bb, info = eng.select()
             for s in range(S):
@@ -242,11 +414,19 @@ def main():
                     eng.expand_backup(p, v)
         eng.choose_and_advance()
         if measure:
-            # finished games leave the device every move (selfplay.py:41) and, with several ranks,
-            # travel to the replay rank as raw records (replaces replay_buffer.py:28-47)
-            raw = eng.drain_finished_bytes()
-            if world > 1:
-                gather_record_bytes(raw, dst=0, device='cpu' if rehearse else dev)
+            hand_over()
+
+    def hand_over():
+        # finished games are handed over every move (selfplay.py:41): on one GPU to the host, as the
+        # reference's dataset sink wants them; with several ranks they stay in device memory and are
+        # gathered on the replay rank over RCCL (replaces replay_buffer.py:28-47)
+        if world > 1:
+            recs, head = eng.take_finished_device()
+            got, flags = gather_records_device(recs, head, dst=0)
+            assert flags == 0 or args.allow_pool_errors, f'engine error bits {flags}'
+            finished_on_dst[0] += int(got.shape[0])
+        else:
+            eng.drain_finished_bytes()
 
     def sync_all():
         if world > 1:
@@ -317,25 +497,30 @@ def main():
                    'mean_select_depth': d, 'leaf_eval_fraction': f,
                    'eval_cache_log2': args.eval_cache_log2 if use_cache else 0,
                    'eval_cache_hit_rate': hits / max(evals, 1),
-                   'games_finished': st1['games'] - st0['games']},
+                   'games_finished': st1['games'] - st0['games'],
+                   'exchange': None if world == 1 else
+                   ('per step: broadcast_packed (kernel-ready weights, one in-place broadcast) + '
+                    'gather_records_device (records device to device)' if packed_wire else
+                    'per step: broadcast_model + gather_records_device'),
+                   'records_gathered_on_rank0': finished_on_dst[0] if world > 1 else None},
     }
     if rank == 0:
         def avg_ms(pairs):
             return sum(a.elapsed_time(b) for a, b in pairs) / len(pairs)
 
         def pmc_traffic(kernel_prefix):
-            """HBM bytes per launch from the committed counter passes of this same command
-            (profiles/r01_pmc_means.json: FETCH_SIZE and WRITE_SIZE in KiB, separate passes;
+            """HBM bytes per launch from the newest committed counter passes of this same command
+            (profiles/rNN_pmc_means.json: FETCH_SIZE and WRITE_SIZE in KiB, separate passes;
             FETCH_SIZE doubled, the gfx950 correction for 16-byte-per-lane reads)."""
             try:
-                pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_means.json')))
+                pm = json.load(open(latest_profile('pmc_means.json')))
                 for fk, wk in (('pmc_fetch', 'pmc_write'), ('pmc_stepwise_fetch', 'pmc_stepwise_write')):
                     fe = [v['FETCH_SIZE']['mean'] for k, v in pm.get(fk, {}).items() if k.startswith(kernel_prefix)]
                     wr = [v['WRITE_SIZE']['mean'] for k, v in pm.get(wk, {}).items() if k.startswith(kernel_prefix)]
                     if fe and wr:
                         return (2.0 * fe[0] + wr[0]) * 1024.0
                 return None
-            except (OSError, KeyError, IndexError, ValueError):
+            except (OSError, KeyError, IndexError, ValueError, TypeError):
                 return None
         bps = bytes_per_sim(d, f)
         if fused_move:
@@ -350,7 +535,7 @@ def main():
                                'leaves_per_launch': (evals - hits) / args.steps,
                                'note': 'search and network phases of all simulations of a move; the search phases '
                                        'do no matrix work'}
-        if net is not None and args.net_impl == 'hip':
+        if net is not None and args.net_impl == 'hip' and net_ev and tree_ev:
             ms = avg_ms(net_ev)
             # leaves one launch evaluates x flops per leaf; the 128-channel kernels take every leaf of
             # the batch, needed or not, and only the needed ones count as algorithmic work
@@ -371,20 +556,56 @@ def main():
                                     'traffic': pmc_traffic('void k_sim_step_p<GameC4, 8, true, true>'),
                                     'algorithmic_bytes_per_launch': bps * G,
                                     'avg_launch_ms': ms, 'bytes_per_sim': bps}
-        elif net is None:
+        elif net is None and tree_ev:
             ms = avg_ms(tree_ev)
             gbs = bps * G * S / (ms * 1e-3) / 1e9
             out['roofline'] = {'kernel': 'k_run_uniform<GameC4>', 'bound': 'hbm', 'achieved': gbs,
                                'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
                                'traffic': None, 'avg_launch_ms': ms, 'bytes_per_sim': bps}
+        if world == 1 and fused_move and not args.no_extras:
+            from alphazero_amd.net import FusedC4NetF32
+            f32 = FusedC4NetF32(net, dev)
+            # (a) the same self-play loop with the fp32 parity kernel evaluating every leaf (stepwise calls)
+            def f32_step():
+                bb, info = eng.begin_move()
+                p, _ = f32(bb, info)
+                eng.apply_root(p)
+                bb, info = eng.select()
+                for s_ in range(S):
+                    p, v = f32(bb, info)
+                    if s_ < S - 1:
+                        bb, info = eng.sim_step(p, v)
+                    else:
+                        eng.expand_backup(p, v)
+                eng.choose_and_advance()
+                eng.drain_finished_bytes()
+            f32_step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                f32_step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / 2
+            out['fp32_net'] = {'value': G / dt, 'unit': 'positions/s', 'ms_per_step': 1e3 * dt, 'steps': 2,
+                               'kernel': 'k_c4net_f32 (v_mfma_f32_32x32x2_f32, every leaf) + k_sim_step_p per simulation',
+                               'note': 'the configuration whose network outputs are within 1e-5 of the reference fp32 net'}
+            # (b) how often the bf16 production path changes a move or a visit vector
+            out['agreement'] = measure_agreement(dev, fused, f32, S)
+            # (c) BASELINE config 4
+            out['config4_leaf_eval'] = config4_leaf_eval(dev)
         if not args.no_cpu_baseline and world == 1:      # the host-CPU baseline is timed at N = 1 only
-            workers = min(16, os.cpu_count() or 1)
+            logical, physical = physical_cores()
+            workers = cpu_share()
             pps, sps, npos, wall = cpu_baseline(args.model, S, args.cpu_seconds, workers)
             try:        # oracle speed / reference-Python speed, measured in the build container (tools/ref_ratio.py)
-                ratio = json.load(open(os.path.join(ROOT, 'profiles', 'r01_ref_vs_oracle_cpu.json')))['oracle_over_reference']
-            except (OSError, KeyError, ValueError):
+                ratio = json.load(open(latest_profile('ref_vs_oracle_cpu.json')))['oracle_over_reference']
+            except (OSError, KeyError, ValueError, TypeError):
                 ratio = None
             out['cpu_baseline'] = {'value': pps, 'unit': 'positions/s', 'sims_per_s': sps, 'cores': workers,
+                                   'host_logical_cpus': logical, 'host_physical_cores': physical,
+                                   'cores_note': 'workers = the CPUs this job owns (affinity mask, capped by '
+                                                 'OMP_NUM_THREADS where the host sets a per-job share); the '
+                                                 'machine-wide counts are given beside it',
                                    'kind': 'port', 'oracle_over_reference_python': ratio,
                                    'reference_python_equivalent': pps / ratio if ratio else None,
                                    'sample': f'{npos} self-play moves ({S} sims each) by the CPU oracle in {wall:.1f} s: '

@@ -75,8 +75,8 @@ typedef struct {
     uint64_t uid;
     int32_t  num_moves;
     int32_t  winner;                                   /* -1 draw, 0, 1      */
-    int32_t  model_version;
-    int32_t  reserved;
+    int32_t  model_version;                            /* current when the game ended   */
+    int32_t  first_model_version;                      /* current when the game started */
     uint8_t  history[AZ_MAX_MOVES + 6];                /* actions            */
     uint8_t  num_edges[AZ_MAX_MOVES + 6];              /* legal moves / move */
     uint32_t visits[AZ_MAX_MOVES][AZ_MAX_ACTIONS];     /* compacted root N   */
@@ -157,7 +157,18 @@ int  az_choose_and_advance(az_engine* e, const double* u, int32_t* action, int32
  * replaces ReplayBufferDataset.add_game (replay_buffer.py:165-167)          */
 int  az_drain_finished(az_engine* e, az_game_record* out_host, int32_t max_records,
                        int32_t* num_out, void* stream);
+/* The same hand-over without leaving the device and without a host synchronisation: up to max_records
+ * finished games are copied to out_dev (DEVICE az_game_record[max_records]), head_dev (DEVICE int32[2])
+ * receives {records copied, error bits as az_engine_error_flags}, the ring is emptied; everything is
+ * ordered on `stream`.  For records that travel on to another rank (gather over RCCL) or into a
+ * device-side replay window (az_examples_from_records).  Replaces replay_buffer.py:165-167.           */
+int  az_take_finished_device(az_engine* e, az_game_record* out_dev, int32_t max_records, int32_t* head_dev, void* stream);
 int  az_get_stats(az_engine* e, az_stats* out_host, void* stream);
+/* Error bits of any game, as seen by the az_drain_finished calls since the last az_reset_games: bit 0 = a
+ * game's node pool ran out (its later simulations are lost), bit 1 = the record ring overflowed (finished
+ * games were dropped: drain more often).  Host-side read, no device work; -1 for a null engine.  The
+ * reference cannot fail this way (it allocates per node and per game).                                */
+int  az_engine_error_flags(const az_engine* e);
 
 /* Training examples of finished games, built on the device: what ReplayBufferDataset.__getitem__
  * (alphazero/replay_buffer.py:113-147) returns for every state of n records, in game-major order.

@@ -88,6 +88,33 @@ def _worker(rank, world, port, out_dir):
         assert sorted(r.uid for r in got) == [0, 1, 1000, 1001, 1002]
         r = [x for x in got if x.uid == 1002][0]
         assert r.history[3] == 4 and r.visits[5][6] == 156 and r.model_version == 5
+    # --- the device-resident forms, on CPU tensors here: records as a fixed-capacity tensor + {count, flags}
+    for counts, flag in (((3, 0), 0), ((2, 5), 2), ((0, 0), 0)):
+        n = counts[rank]
+        cap = 12
+        buf = torch.zeros(cap, D.RECORD_BYTES, dtype=torch.uint8)
+        if n:
+            buf[:n] = torch.from_numpy(D.records_to_bytes(_fake_records(rank, n)))
+        buf[n:] = 0xEE                                            # stale tail of the ring copy must not travel
+        head = torch.tensor([n, flag if rank == 1 else 0], dtype=torch.int32)
+        got, flags = D.gather_records_device(buf, head, dst=0)
+        assert flags == flag
+        if rank == 0:
+            assert got.shape == (sum(counts), D.RECORD_BYTES)
+            uids = [r.uid for r in D.bytes_to_records(got.numpy())]
+            assert uids == [i for i in range(counts[0])] + [1000 + i for i in range(counts[1])]
+        else:
+            assert got.shape[0] == 0
+    # --- kernel-ready weights: one in-place broadcast of the evaluator's wire buffer
+
+    class Wire:                                                  # what broadcast_packed needs of a FusedC4Net
+        def __init__(self, fill, blocks):
+            self.wire = torch.full((256 + 1000,), fill, dtype=torch.uint8)
+            self.num_blocks = blocks
+    net = Wire(7 if rank == 0 else 9, 6 if rank == 0 else 1)
+    where = net.wire.data_ptr()
+    assert D.broadcast_packed(net, 41 if rank == 0 else -5, src=0) == 41
+    assert net.num_blocks == 6 and net.wire.data_ptr() == where and torch.all(net.wire[256:] == 7)
     dist.barrier()
     dist.destroy_process_group()
     open(os.path.join(out_dir, f'ok{rank}'), 'w').write('ok')
@@ -168,3 +195,29 @@ def test_two_rank_gloo_sharding_broadcast_gather(tmp_path):
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(tmp_path / 'ok0') and os.path.exists(tmp_path / 'ok1')
+
+
+def test_bench_launches_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` with no launcher around it must start N ranks itself, through
+    torch.distributed.run on 127.0.0.1, passing its own arguments on, before this process has touched a
+    GPU (the parent only relays); with WORLD_SIZE set (the launcher's children) it must not."""
+    import importlib
+    import subprocess
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module('bench')
+    calls = []
+    monkeypatch.setattr(subprocess, 'call', lambda cmd, env=None: calls.append((cmd, env)) or 0)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '3', '--warmup', '1'])
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: (_ for _ in ()).throw(AssertionError('GPU touched')))
+    try:
+        bench.main()
+    except SystemExit as e:
+        assert e.code == 0
+    else:
+        raise AssertionError('the parent must exit with the launcher status')
+    (cmd, env), = calls
+    assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1'] and '--nproc-per-node=4' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert cmd[-6:] == ['--gpus', '4', '--steps', '3', '--warmup', '1'] and cmd[-7].endswith('bench.py')
+    assert env.get('HSA_ENABLE_IPC_MODE_LEGACY') == '0'

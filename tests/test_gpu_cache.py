@@ -198,15 +198,16 @@ def test_fused_move_equals_the_stepwise_loop(G, S):
     assert hits > 0
 
 
-def test_full_size_move_properties():
-    """The benchmark's own shape (8 192 games x 800 simulations, 6x32 network, one launch per move): the
+@pytest.mark.parametrize('G,S', [(8192, 800), (1024, 200)])
+def test_full_size_move_properties(G, S):
+    """The benchmark's own shapes (8 192 games x 800 simulations, and 1 024 x 200, the single-GPU
+    configuration; 6x32 network, one launch per move): the
     size-independent properties of a search -- every simulation is accounted for, a fresh root's visit
     counts sum to S and a re-used root's to at least S, no pool is exhausted -- and the stepwise loop
     agrees bit for bit on the last move."""
     from alphazero_amd import engine as E
     from alphazero_amd.models import AlphaZeroC4
     from alphazero_amd.net import FusedC4Net
-    G, S = 8192, 800
     torch.manual_seed(0)
     net = FusedC4Net.from_module(AlphaZeroC4(6, 32).eval().cuda(), 'cuda')
     engs = [E.SelfPlayEngine(E._lib.GAME_C4, G, S, exploration_depth=4, reuse_search_tree=True, seed=3, device=0)

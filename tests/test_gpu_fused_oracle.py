@@ -1,0 +1,95 @@
+"""The one-launch-per-move kernel (az_c4_move_fused: what bench.py times) against the CPU oracle
+directly, with the network in the loop on both sides.
+
+HIP side: az_apply_root(eta) -> az_c4_move_fused -> az_choose_and_advance(u) for G concurrent games.
+Oracle side: the same games one at a time (oracle/az_oracle.c, alphazero/mcts.py:110-158 and
+selfplay.py:24-38 restated), every leaf evaluated by the same HIP network kernel on a batch of one --
+its rows are pure functions of the position (test_gpu_net.py::test_fused_forward_is_independent_of_batch_shape),
+so both sides see identical leaf evaluations.  Done = every move, every visit vector and the bits of the
+root's W and P are equal."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as orc
+from helpers import load_lut
+
+pytestmark = pytest.mark.gpu
+
+
+def _single_leaf_evaluator(net, memo):
+    """oracle evaluator: (game, history, valid) -> (p over the legal moves, v) from the HIP network."""
+    from alphazero_amd import engine as E
+
+    def fn(game, hist, valid):
+        key = bytes(hist)
+        if key not in memo:
+            bb, _ = E.positions_from_history(1, [hist])
+            p, v = net(bb, None)
+            memo[key] = (p[0].cpu().numpy().copy(), float(v[0].item()))
+        p, v = memo[key]
+        return p[valid], v
+    return fn
+
+
+@pytest.mark.parametrize('G,S,moves,depth', [(64, 48, 9, 4), (64, 200, 4, 2), (100, 33, 5, 3)])
+def test_fused_move_kernel_matches_the_oracle(G, S, moves, depth):
+    from alphazero_amd import engine as E
+    from alphazero_amd.models import AlphaZeroC4
+    from alphazero_amd.net import FusedC4Net
+    A = 7
+    torch.manual_seed(17)
+    net = FusedC4Net.from_module(AlphaZeroC4(6, 32).eval().cuda(), 'cuda')
+    lut_np = load_lut()
+    rng = np.random.RandomState(1000 + G + S)
+    etas = rng.dirichlet([0.3] * A, size=(G, moves))          # slot-indexed; the first n_edges are used
+    us = rng.random_sample((G, moves))
+
+    # ---- HIP: all games at once
+    eng = E.SelfPlayEngine(E._lib.GAME_C4, G, S, exploration_depth=depth, reuse_search_tree=True, lut=lut_np, device=0)
+    got = []
+    for mv in range(moves):
+        bb, info = eng.begin_move()
+        p, _ = net(bb, info)
+        eng.apply_root(p, torch.from_numpy(np.ascontiguousarray(etas[:, mv])).cuda())
+        eng.move_fused(net)
+        roots = []
+        for g in range(G):
+            img, root = eng.get_tree(g)
+            n = int(img[root, A, 0])
+            roots.append((img[root, :n, 0].copy(), img[root, :n, 1].copy(), img[root, :n, 2].copy()))
+        act, ne, vis, win = eng.choose_and_advance(torch.from_numpy(np.ascontiguousarray(us[:, mv])).cuda())
+        got.append((act.cpu().numpy().copy(), ne.cpu().numpy().copy(), vis.cpu().numpy().copy(), roots))
+    assert eng.stats()['errors'] == 0 and eng.error_flags() == 0
+    eng.close()
+
+    # ---- oracle: one game at a time, the same eta / u per (game, move)
+    lut = orc.make_lut_array(lut_np)
+    cfg = orc.make_config(orc.C4, S, depth, True, lut)
+    memo = {}
+    ev = orc.eval_from_python(_single_leaf_evaluator(net, memo))
+    checked = 0
+    for k in range(G):
+        hist, tree = [], orc.Node()
+        top = tree
+        for mv in range(moves):
+            if orc.terminal(orc.C4, hist):
+                break                                           # the slot restarted with a new game
+            nv = len(orc.valid_actions(orc.C4, hist))
+            orc.run_mcts(cfg, hist, tree, ev, orc.dirichlet_from_list([etas[k, mv, :nv]]))
+            N, W, P = tree.edges()
+            act, ne, vis, roots = got[mv]
+            assert int(ne[k]) == len(N), (k, mv)
+            assert list(vis[k, :len(N)]) == list(N), (k, mv, list(N), list(vis[k]))
+            assert roots[k][0].tolist() == list(N), (k, mv)
+            assert roots[k][1].tobytes() == W.view(np.uint32).tobytes(), (k, mv, 'W')
+            assert roots[k][2].tobytes() == P.view(np.uint32).tobytes(), (k, mv, 'P')
+            ai = tree.sample_action(us[k, mv]) if len(hist) < depth else tree.greedy_action()
+            a = orc.valid_actions(orc.C4, hist)[ai]
+            assert a == int(act[k]), (k, mv)
+            hist.append(a)
+            tree = tree.traverse(ai)
+            tree.kill_siblings()
+            checked += 1
+        del top
+    assert checked >= G * min(moves, 7) * 0.9

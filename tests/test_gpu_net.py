@@ -154,6 +154,61 @@ def test_trunk128_bf16_matches_torch_fp32(blocks, n):
     assert dp < 2e-2 and dv < 2e-2
 
 
+def test_trunk128_full_batch_of_16384_leaves():
+    """The 10x128 leaf-evaluation configuration at its full batch (16 384 leaves: 2 731 tower workgroups,
+    and the listed path through k_compact128): 512 sampled rows against the fp32 torch net within the
+    bf16 tolerance, bit-equal to the same positions evaluated in batches of 130, and bit-equal again when
+    the batch is evaluated through a leaf list that skips 15 % of the rows."""
+    from alphazero_amd import engine as E
+    from alphazero_amd.models import AlphaZeroC4
+    from alphazero_amd.net import C4Net128
+    n, blocks = 16384, 10
+    torch.manual_seed(50)
+    model = AlphaZeroC4(blocks, 128).eval()
+    _randomize_bn(model, 8)
+    with torch.no_grad():               # keep the shared-block tower from amplifying activations
+        model._tower[0]._bn2.weight.mul_(0.5)
+    base = _random_positions(1500, 0)
+    rng = np.random.RandomState(0)
+    pick = rng.randint(0, len(base), size=n)
+    hists = [base[i] for i in pick]
+    bb, nm = E.positions_from_history(1, hists)
+    legal, _, _ = E.game_query(1, bb, nm)
+    net = C4Net128(model, 'cuda', max_leaves=n)
+    p, v = net(bb)
+    p, v = p.clone(), v.clone()
+    rows = torch.from_numpy(np.sort(rng.choice(n, size=512, replace=False))).cuda()
+    # (a) the same positions in small batches: the rows are pure functions of the position
+    small = C4Net128(model, 'cuda', max_leaves=130)
+    for lo in range(0, 512, 130):
+        idx = rows[lo:lo + 130]
+        ps, vs = small(bb[idx].contiguous())
+        assert torch.equal(ps, p[idx]) and torch.equal(vs, v[idx])
+    # (b) fp32 torch on the sampled rows
+    x, valid = E.render(1, bb[rows].contiguous())
+    with torch.no_grad():
+        logits, vref = model(x.cpu(), valid.cpu())
+    valid = valid.cpu()
+    pref = torch.zeros_like(logits)
+    for i in range(rows.numel()):
+        pref[i, valid[i]] = torch.softmax(logits[i, valid[i]], 0)
+    dp = (p[rows].cpu() - pref).abs().max().item()
+    dv = (v[rows].cpu() - vref.reshape(-1)).abs().max().item()
+    print('10x128 at 16384 leaves: max |dp|', dp, 'max |dv|', dv)
+    assert torch.all(p[rows].cpu()[~valid] == 0)
+    assert dp < 2e-2 and dv < 2e-2
+    assert torch.allclose(p.sum(1), torch.ones(n, device='cuda'), atol=1e-4)
+    # (c) the listed path: 85 % of the rows need the network, the rest keep their contents
+    kind = torch.from_numpy(rng.choice([1, 2, 3, 0], size=n, p=[0.8, 0.1, 0.05, 0.05]).astype(np.int32)).cuda()
+    info = ((legal << 16) | kind).to(torch.int32)
+    net._p.fill_(-7.0)
+    net._v.fill_(-7.0)
+    p2, v2 = net(bb, info)
+    act = (kind == 1) | (kind == 3)
+    assert torch.equal(p2[act], p[act]) and torch.equal(v2[act], v[act])
+    assert torch.all(p2[~act] == -7.0) and torch.all(v2[~act] == -7.0)
+
+
 def test_trunk128_evaluates_only_leaves_that_need_it():
     """With leaf_info the 128-channel path lists the EVAL / ROOT leaves first and runs only those; their
     rows equal the dense evaluation bit for bit, the other rows are left alone."""

@@ -352,3 +352,12 @@ def test_tictactoe_solver_known_line():
         scores, v = game.solve()
         assert len(game.valid_actions) == len(scores) and scores == want['scores'] and v == want['v']
     assert table[(0, 2)]['scores'] == [-1, 2, 0, 0, 2, 0, 2] and table[(0, 2, 8, 4, 6, 7)]['scores'] == [0, 2, -1]
+
+
+def test_worker_refuses_the_eval_cache_with_a_callers_evaluator():
+    """az_sim_step answers cached leaves by writing rows of the evaluator's own buffers, a contract only the
+    built-in HIP networks keep: the combination is refused before anything is built."""
+    import pytest
+    from alphazero_amd.selfplay import SelfPlayWorker
+    with pytest.raises(ValueError, match='built-in HIP networks'):
+        SelfPlayWorker(None, None, None, 'cpu', evaluator=lambda bb, info: None, eval_cache_log2=12)
