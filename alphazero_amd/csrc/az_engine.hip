@@ -1117,7 +1117,39 @@ static inline dim3 group_grid(int G, int gs) {
         else return az_fail("unknown game id");                       \
     } while (0)
 
+// ---------------------------------------------------------------------------
+// Scratch of az_c4_move_fused_static: the four per-game staging arrays that az_c4_move_fused takes from its
+// caller (leaf positions, leaf words, priors, values passed between the search and network phases of a
+// workgroup), for up to FUSED_STATIC_MAX_GAMES games, in device memory that belongs to the library image --
+// nothing is allocated to use it.  Each GPU holds its own copy at its own address; host code only ever uses
+// the per-device address looked up once in az_engine_create (the array's name is not a device pointer on the
+// host side).
+// ---------------------------------------------------------------------------
+#define FUSED_STATIC_MAX_GAMES 16384
+#define FS_OFF_BB   0                                               // uint64 [MAX][2]
+#define FS_OFF_INFO (FS_OFF_BB + FUSED_STATIC_MAX_GAMES * 16)       // int32  [MAX]
+#define FS_OFF_P    (FS_OFF_INFO + FUSED_STATIC_MAX_GAMES * 4)      // float  [MAX][7]
+#define FS_OFF_V    (FS_OFF_P + FUSED_STATIC_MAX_GAMES * 28)        // float  [MAX]
+#define FS_BYTES    (FS_OFF_V + FUSED_STATIC_MAX_GAMES * 4)         // 832 KiB
+static __device__ __align__(256) uint8_t scratch[FS_BYTES];
+#define MAX_DEVICES 64
+static uint8_t* g_scratch_ptr[MAX_DEVICES];                         // device address of `scratch` per device, or null
+static_assert(FS_OFF_INFO % 256 == 0 && FS_OFF_P % 256 == 0 && FS_OFF_V % 256 == 0, "scratch sub-arrays stay aligned");
+
 static std::atomic<unsigned long long> g_fused_attr_done{0};        // bit d = k_c4_move_fused may use its LDS on device d
+
+// with device `dev` current: look the array's address up once per device, and give the kernel its dynamic-LDS
+// attribute here, so that az_c4_move_fused_static itself is nothing but a launch
+static int scratch_setup(int dev) {
+    if (int rc = az_set_kernel_lds(reinterpret_cast<const void*>(k_c4_move_fused), LDS_BYTES, g_fused_attr_done)) return rc;
+    if (dev < 0 || dev >= MAX_DEVICES) return 0;                    // az_c4_move_fused_static refuses such a device
+    if (g_scratch_ptr[dev]) return 0;
+    void* ptr = nullptr;
+    HIPCHK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) return az_fail("hipGetSymbolAddress(scratch) returned null");
+    g_scratch_ptr[dev] = static_cast<uint8_t*>(ptr);
+    return 0;
+}
 
 extern "C" {
 
@@ -1159,6 +1191,7 @@ int az_engine_create(const az_engine_config* cfg, az_engine** out) {
     int cus = 0;
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device));
     if (cus <= 0) return az_fail("device reports no compute units");
+    if (int rc = scratch_setup(cfg->device)) return rc;
     az_engine* e = new az_engine();
     e->cfg = *cfg;
     e->A = cfg->game == AZ_GAME_C4 ? GameC4::A : GameTTT::A;
@@ -1364,6 +1397,19 @@ int az_c4_move_fused(az_engine* e, const uint8_t* blob, int32_t num_blocks, uint
     if (!e || !blob || !leaf_bb || !leaf_info || !p || !v) return az_fail("null argument");
     ENGINE_SCOPE(e);
     return fused_launch(e, blob, num_blocks, leaf_bb, leaf_info, p, v, (hipStream_t)stream);
+}
+
+int az_c4_move_fused_static(az_engine* e, const uint8_t* blob, int32_t num_blocks, void* stream) {
+    if (!e || !blob) return az_fail("null argument");
+    ENGINE_SCOPE(e);
+    if (e->d.G > FUSED_STATIC_MAX_GAMES)
+        return az_fail("az_c4_move_fused_static: more than 16384 games (the size of the built-in staging area)");
+    const int dev = e->cfg.device;
+    uint8_t* base = (dev >= 0 && dev < MAX_DEVICES) ? g_scratch_ptr[dev] : nullptr;
+    if (!base) return az_fail("az_c4_move_fused_static: no staging area on this device (ordinal beyond 63)");
+    return fused_launch(e, blob, num_blocks, reinterpret_cast<uint64_t*>(base + FS_OFF_BB),
+                        reinterpret_cast<int32_t*>(base + FS_OFF_INFO), reinterpret_cast<float*>(base + FS_OFF_P),
+                        reinterpret_cast<float*>(base + FS_OFF_V), (hipStream_t)stream);
 }
 
 int az_run_sims_uniform(az_engine* e, int32_t num_sims, void* stream) {

@@ -146,6 +146,11 @@ class SelfPlayEngine:
         check(self.lib.az_c4_move_fused(self.h, ptr(net.blob), int(net.num_blocks), ptr(self.leaf_bb),
                                         ptr(self.leaf_info), ptr(p), ptr(v), self._stream()))
 
+    def move_fused_static(self, net):
+        """move_fused through the entry point that allocates nothing and takes no staging buffers
+        (az_c4_move_fused_static: up to 16384 games, one shared staging area per GPU)."""
+        check(self.lib.az_c4_move_fused_static(self.h, ptr(net.blob), int(net.num_blocks), self._stream()))
+
     def run_sims_uniform(self, num_sims):
         check(self.lib.az_run_sims_uniform(self.h, int(num_sims), self._stream()))
 

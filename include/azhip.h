@@ -256,6 +256,18 @@ int  az_c4net128_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uin
 int  az_c4_move_fused(az_engine* e, const uint8_t* blob, int32_t num_blocks, uint64_t* leaf_bb,
                       int32_t* leaf_info, float* p, float* v, void* stream);
 
+/* az_c4_move_fused without its four staging arguments and without any allocation.  No counterpart in the
+ * reference; for callers that cannot allocate device memory or pass a workspace: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  The staging arrays (leaf positions, leaf words, priors,
+ * values that travel between the search and network phases) live in a fixed area of device memory that is part
+ * of the library image, 832 KiB per GPU, sized for engines of up to 16384 games: a larger engine is refused
+ * with an error.  The call issues one kernel launch on `stream` and nothing else (no hipMalloc / hipFree, no
+ * memset: every staging word is written by the kernel before it is read, so stale contents of the previous
+ * call are harmless).  All engines on one GPU share that GPU's area: two calls that overlap in time on one GPU
+ * race; calls ordered on one stream, or on different GPUs, do not.  Trees, visit counts and records are
+ * bit-identical to az_c4_move_fused.                                                                     */
+int  az_c4_move_fused_static(az_engine* e, const uint8_t* blob, int32_t num_blocks, void* stream);
+
 /* Tic-tac-toe network (alphazero/models.py:70-87 with shape_in [2,3,3], shape_out [9], as in
  * alphazero/config/tictactoe.yaml:4-11) entirely in fp32, one launch: stem, shared residual block x
  * num_blocks, policy head with soft-max over the empty squares (mcts.py:101-106), value head.
