@@ -797,13 +797,12 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
                 float* v, int num_sims, int gpw) {
     constexpr int GS = 8;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    uint8_t* bufX = lds;
-    uint8_t* bufY = lds + ACT_BYTES;
-    uint8_t* scr = lds + 2 * ACT_BYTES;
+    uint8_t* wlds = lds;
+    uint8_t* scr = lds + W_BYTES;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     {
-        uint4* z = reinterpret_cast<uint4*>(lds);
-        for (int i = tid; i < LDS_BYTES / 16; i += NTHREADS) z[i] = make_uint4(0, 0, 0, 0);
+        uint4* z = reinterpret_cast<uint4*>(scr);
+        for (int i = tid; i < S_BYTES / 16; i += NTHREADS) z[i] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
     if (tid < 100) reinterpret_cast<float*>(scr + S_BIAS)[tid] = reinterpret_cast<const float*>(blob + OFF_BIAS)[tid];
@@ -812,12 +811,7 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
         reinterpret_cast<float*>(scr + S_W2)[tid] = reinterpret_cast<const float*>(blob + OFF_W2)[tid];
     }
     if (tid < 64) reinterpret_cast<float*>(scr + S_BP)[tid] = reinterpret_cast<const float*>(blob + OFF_BP)[tid];
-    Weights w1, w2;
-#pragma unroll
-    for (int s = 0; s < 18; ++s) {
-        w1.f[s] = frag_ptr(blob, OFF_WF, lane)[s * 64];
-        w2.f[s] = frag_ptr(blob, OFF_WF + 18 * 1024, lane)[s * 64];
-    }
+    load_tower_weights(blob, wlds, tid);         // once per move; ordered before their first use by the barriers below
 
     // search lanes: thread t serves game g_base + t / 8 (gpw <= 64 games per workgroup).  Everything a
     // search phase needs is re-derived from an opaque copy of the thread index at its start, so no
@@ -884,7 +878,7 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
         __syncthreads();
         const int nrounds = wtot[0];
         TICK(t_list);
-        net_rounds(blob, num_blocks, leaf_bb, p, v, w1, w2, bufX, bufY, scr, nrounds, tid, wave, lane);
+        net_rounds(blob, num_blocks, leaf_bb, p, v, wlds, scr, nrounds, tid, wave, lane);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");        // (p, v) written by the head phase
         __syncthreads();
         TICK(t_net);

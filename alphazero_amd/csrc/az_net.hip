@@ -4,27 +4,13 @@
 // (stem conv, tower of one residual block applied num_blocks times, policy and value
 // heads, landing-cell gather, soft-max over legal columns) runs in ONE kernel for up to
 // 32 trunk channels.  A workgroup (one per CU, 8 waves) takes its leaf positions straight
-// from their bitboards, two boards per wave at a time, keeps every activation in LDS from
-// the first conv to the last and writes only p[7] and v per leaf: HBM traffic is 16 B in
+// from their bitboards, two boards per wave at a time, keeps every activation of the trunk in
+// registers (az_net_dev.h) and writes only p[7] and v per leaf: HBM traffic is 16 B in
 // and 32 B out per leaf, so the kernel is bounded by the matrix-core rate, not by memory.
 //
-// Every contraction is an MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulate), oriented
-// D[out][pos] = sum_k Wt[out][k] X[k][pos]:
-//   * A = weights.  The two tower convs' fragments stay in registers for the whole kernel
-//     (144 VGPRs per lane); stem / head fragments are small and fetched when used.
-//   * B = activations, one ds_read_b128 per MFMA.  The stem's B operand is built in
-//     registers from the two bitboards (K = 9 taps x 2 planes = 18, padded to 32).
-//   * D puts the position on the lane and 4 consecutive channels in 4 registers, so the
-//     epilogue (residual add, ReLU, bf16) writes 8 bytes per ds_write_b64.
 // Batch-norm (eval mode) is folded into weights and a per-channel bias on the host; the
-// bias is the accumulator's initial value.
-//
-// LDS activation image: positions on an 8-wide grid, 80 bytes apart (32 bf16 channels +
-// 16 B pad: 5 slots of 16 B, coprime with the 16 slots of a bank row, so the 16 lanes of a
-// ds_read_b128 group always land on 16 different slots).  Board b owns 56 positions: one
-// zero row, then 6 rows of 7 cells + 1 zero cell; the zero row of board b+1 closes board b.
-// A 3x3 tap is therefore a constant byte offset folded into the ds_read instruction; the
-// 8th column is computed like a cell and its result is stored to a dump row instead.
+// bias is the accumulator's initial value.  The fully connected heads run once per round for
+// the whole workgroup on v_mfma_f32_32x32x16_bf16 from small planes in LDS.
 #include "az_net_dev.h"
 #include "az_host.h"
 
@@ -33,20 +19,19 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
              const int32_t* __restrict__ leaf_info, int n, float* __restrict__ p_out, float* __restrict__ v_out,
              int grid_shift) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    uint8_t* bufX = lds;                       // conv1 output
-    uint8_t* bufY = lds + ACT_BYTES;           // block input and output
-    uint8_t* scr = lds + 2 * ACT_BYTES;
+    uint8_t* wlds = lds;                       // tower weights
+    uint8_t* scr = lds + W_BYTES;
     float* sbias = reinterpret_cast<float*>(scr + S_BIAS);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 
-    // zero everything once: padding cells and the k-padding of the head planes are never written
-    // again, and an empty entry of the task list is 0 (entries hold leaf index + 1)
+    // zero the scratch once: the k-padding of the head planes is never written again, and an empty
+    // entry of the task list is 0 (entries hold leaf index + 1)
     {
-        uint4* z = reinterpret_cast<uint4*>(lds);
-        for (int i = tid; i < LDS_BYTES / 16; i += NTHREADS) z[i] = make_uint4(0, 0, 0, 0);
+        uint4* z = reinterpret_cast<uint4*>(scr);
+        for (int i = tid; i < S_BYTES / 16; i += NTHREADS) z[i] = make_uint4(0, 0, 0, 0);
     }
     // Memory requests go out in the order in which their data is needed: the small head / bias tables,
-    // then this thread's slice of leaf_info, and only then the 36 KB of tower weights per wave (loads
+    // then this thread's slice of leaf_info, and only then the workgroup's 36 KB of tower weights (loads
     // return in order, so whatever is waited for first must not queue behind the weights).
     float t_bias = 0.0f, t_b1 = 0.0f, t_w2 = 0.0f, t_bp = 0.0f;
     if (tid < 100) t_bias = reinterpret_cast<const float*>(blob + OFF_BIAS)[tid];
@@ -72,12 +57,7 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
     int4 kfirst[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) kfirst[q] = (leaf_info && 4 * q < per) ? load4(g0 + 4 * q) : make_int4(0, 0, 0, 0);
-    Weights w1, w2;
-#pragma unroll
-    for (int s = 0; s < 18; ++s) {
-        w1.f[s] = frag_ptr(blob, OFF_WF, lane)[s * 64];
-        w2.f[s] = frag_ptr(blob, OFF_WF + 18 * 1024, lane)[s * 64];
-    }
+    load_tower_weights(blob, wlds, tid);
     __syncthreads();
     if (tid < 100) sbias[tid] = t_bias;
     if (tid < 256) {
@@ -170,7 +150,7 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
         nrounds = (min(na, MAXIT * 2) + 3) >> 2;
     }
 
-    net_rounds(blob, num_blocks, leaf_bb, p_out, v_out, w1, w2, bufX, bufY, scr, nrounds, tid, wave, lane);
+    net_rounds(blob, num_blocks, leaf_bb, p_out, v_out, wlds, scr, nrounds, tid, wave, lane);
 }
 
 extern "C" {

@@ -1,6 +1,26 @@
 // Device-side building blocks of the fused Connect Four network (types, LDS / blob layout, stem,
 // 3x3 convolution, epilogues): shared by the stand-alone network kernel (az_net.hip) and by kernels that
 // run the network inside a larger launch.
+//
+// A wave takes two boards at a time through stem, tower and the 1x1 head convs with every activation in
+// REGISTERS.  Contractions are v_mfma_f32_16x16x32_bf16, oriented D[out ch][pos] = sum_k Wt[out ch][k] X[k][pos]:
+//   * the 16 positions of a tile are one board row of both boards: lanes p = 0..7 hold cells x = 0..7 of row y
+//     of the first board, p = 8..15 those of the second (x = 7 is a pad cell that is kept at zero).  A tile's
+//     B operand is ONE fragment: lane (p, q = lane / 16) holds channels 8q..8q+7 of position p -- all 32
+//     channels of a tap are one MFMA k-step.  An activation tensor of the two boards is 6 such fragments
+//     (24 registers).
+//   * a 3x3 tap at dy = +-1 reads the neighbouring row's fragment (another register; rows -1 and 6 do not
+//     exist, so those MFMAs are simply not issued), a tap at dx = +-1 reads the row's fragment shifted by one
+//     lane inside its 16-lane DPP row (row_shr:1 / row_shl:1 with zero fill; the pad cell supplies the zero
+//     between the two boards).  No activation is ever written to or read from LDS in the tower.
+//   * output channels are split over two MFMAs per tap in the order that makes D land in B's layout: MFMA
+//     "half" h computes channels 8g + 4h + i (g = 0..3, i = 0..3), so lane (p, q) receives channels 8q + 4h + i
+//     -- after both halves exactly the eight channels its B fragment holds.  The epilogue (residual, ReLU,
+//     bf16) is lane-local: no transposition, no cross-lane traffic.
+//   * weights are the A operand: 18 fragments per conv (9 taps x 2 halves), kept in LDS (36 KB for both tower
+//     convs, filled once per launch) and streamed one ds_read_b128 per fragment; a fragment feeds up to six
+//     MFMAs (one per row).  The twelve accumulators of a conv (6 rows x 2 halves) are independent, so
+//     consecutive MFMAs never wait for each other.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -8,21 +28,14 @@
 #include "../../include/azhip.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-#define TB 16                     // boards in the LDS images: two per wave
-#define PSTRIDE 80                // bytes per position
-#define BOARD_POS 56              // positions per board (zero row + 6 rows of 8)
-#define POS0 9                    // guard + zero row
-#define BOARD_PAD 128             // bytes skipped before every board, see board_off
-#define NPOS_TOTAL (1 + TB * BOARD_POS + 8 + 1)
-#define ACT_BYTES (((NPOS_TOTAL * PSTRIDE + TB * BOARD_PAD) + 255) / 256 * 256)
 #define NTHREADS 512
-#define TILES_PER_WAVE 3          // TB*48/32 = 24 tiles of 32 positions over 8 waves
+#define ROWS 6                    // board rows = tiles of a two-board task
 
-// LDS scratch after the two activation images
+// LDS: tower weights, then scratch
+#define W_BYTES (2 * 18 * 1024)               // [2 convs][9 taps][2 halves][64 lanes][8] bf16
 #define S_BIAS 0                              // float[3][32] conv biases + head bias [4]
 #define S_B1 512                              // float[256] value FC1 bias
 #define S_W2 (S_B1 + 1024)                    // float[256] value FC2 weights
@@ -34,16 +47,15 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define MAXIT 8                               // wave-tasks per wave per launch (n <= 32768)
 #define S_TL (S_PW + 8 * PW_BYTES)            // int [8 waves][MAXIT][2] leaf index of each board
 #define S_WT (S_TL + 8 * MAXIT * 2 * 4)       // int [16] scan scratch
-#define S_DUMP (S_WT + 64)                    // 64 B per wave: landing place for results of zero cells
-#define S_HG (S_DUMP + 8 * 64)                // int [32] leaf index of each head column
+#define S_HG (S_WT + 64)                      // int [32] leaf index of each head column
 #define S_BYTES (S_HG + 128)
-#define LDS_BYTES (2 * ACT_BYTES + S_BYTES)
+#define LDS_BYTES (W_BYTES + S_BYTES)
 
 // blob layout (bytes); must match alphazero_amd/net.py
-#define OFF_SF 0                                   // stem      [2][64][8] bf16
-#define OFF_WF (OFF_SF + 2 * 1024)                 // c1, c2    [2][18][64][8] bf16
-#define OFF_HF (OFF_WF + 2 * 18 * 1024)            // 1x1 heads [2][64][8] bf16
-#define OFF_F1 (OFF_HF + 2 * 1024)                 // value FC1 [8][3][64][8] bf16
+#define OFF_SF 0                                   // stem      [2 halves][64][8] bf16 (16x16x32 A fragments)
+#define OFF_WF (OFF_SF + 2 * 1024)                 // c1, c2    [2][9 taps][2 halves][64][8] bf16
+#define OFF_HF (OFF_WF + W_BYTES)                  // 1x1 heads [64][8] bf16 (rows 0,1 policy planes, 2 value plane)
+#define OFF_F1 (OFF_HF + 1024)                     // value FC1 [8][3][64][8] bf16 (32x32x16 A fragments)
 #define OFF_PF (OFF_F1 + 8 * 3 * 1024)             // policy FC [2][6][64][8] bf16
 #define OFF_BIAS (OFF_PF + 2 * 6 * 1024)           // float [3][32] stem, c1, c2 ; then [4] heads
 #define OFF_BP (OFF_BIAS + 100 * 4)                // float [64] policy FC bias
@@ -53,31 +65,19 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define BLOB_BYTES (OFF_B2 + 16)
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
-
-// Byte offset of cell-grid position o (0..47) of board b in an activation image.  A tile of 32
-// positions can straddle two boards; going from one board to the next skips 8 positions (the zero
-// row), i.e. 40 slots of 16 B = 8 mod 16, which would put the two halves of a ds_read_b128 lane
-// group on the same slots.  128 bytes (8 slots) of never-written padding per board make the step a
-// multiple of 16 slots again; the padding extends the zero row, so taps across it still read zeros.
-__device__ __forceinline__ int board_off(int b, int o) { return (b * BOARD_POS + POS0 + o) * PSTRIDE + b * BOARD_PAD; }
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
-
-struct Weights { bf16x8 f[18]; };
 
 __device__ __forceinline__ const bf16x8* frag_ptr(const uint8_t* blob, int off, int lane) {
     return reinterpret_cast<const bf16x8*>(blob + off) + lane;
 }
 
-// accumulator = per-channel bias: register r holds channel (r&3) + 8*(r>>2) + 4*h
-__device__ __forceinline__ f32x16 bias_acc(const float* bias, int h) {
-    f32x16 acc;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(bias + 8 * g + 4 * h);
-        acc[4 * g] = b[0]; acc[4 * g + 1] = b[1]; acc[4 * g + 2] = b[2]; acc[4 * g + 3] = b[3];
-    }
-    return acc;
+// the tower weights go from the blob to LDS once per launch; every thread of the workgroup takes part
+__device__ __forceinline__ void load_tower_weights(const uint8_t* blob, uint8_t* wlds, int tid) {
+    const uint4* src = reinterpret_cast<const uint4*>(blob + OFF_WF);
+    uint4* dst = reinterpret_cast<uint4*>(wlds);
+    for (int i = tid; i < W_BYTES / 16; i += NTHREADS) dst[i] = src[i];
 }
 
 // bf16(ReLU(a)), bf16(ReLU(b)) packed in one dword: convert first, then clamp the two bit patterns
@@ -93,105 +93,103 @@ __device__ __forceinline__ uint32_t relu_bf16x2(float a, float b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, y), z));
 }
 
-// (+ residual from q) -> ReLU -> bf16 -> q, 4 channels per 8-byte store; q = the lane's position
-// (channel 0) plus h * 8
+// activations of a two-board task: fragment y = row y of both boards, lane (p, q) = channels 8q..8q+7 of cell p
+struct Act { bf16x8 t[ROWS]; };
+
+// the row's fragment as seen one cell to the left (LEFT: lane p reads lane p - 1) or to the right, zero at
+// the ends of the 16-lane row
+template <bool LEFT>
+__device__ __forceinline__ bf16x8 shift_cell(const bf16x8& v) {
+    constexpr int CTRL = LEFT ? 0x111 : 0x101;               // row_shr:1 / row_shl:1
+    const uint4 u = __builtin_bit_cast(uint4, v);
+    uint4 r;
+    r.x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u.x, CTRL, 0xF, 0xF, true);
+    r.y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u.y, CTRL, 0xF, 0xF, true);
+    r.z = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u.z, CTRL, 0xF, 0xF, true);
+    r.w = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u.w, CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+// (+ residual) -> ReLU -> bf16, the two accumulator halves of one row -> its fragment; `keep` is all ones on
+// cell lanes and zero on the pad lanes
 template <bool RES>
-__device__ __forceinline__ void store_tile(const f32x16& acc, uint8_t* q) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        float x0 = acc[4 * g], x1 = acc[4 * g + 1], x2 = acc[4 * g + 2], x3 = acc[4 * g + 3];
-        if (RES) {
-            const uint2 r = *reinterpret_cast<const uint2*>(q + g * 16);
-            x0 += __uint_as_float(r.x << 16); x1 += __uint_as_float(r.x & 0xFFFF0000u);
-            x2 += __uint_as_float(r.y << 16); x3 += __uint_as_float(r.y & 0xFFFF0000u);
-        }
-        *reinterpret_cast<uint2*>(q + g * 16) = make_uint2(relu_bf16x2(x0, x1), relu_bf16x2(x2, x3));
+__device__ __forceinline__ bf16x8 finish_row(f32x4 c0, f32x4 c1, const bf16x8& res, uint32_t keep) {
+    if (RES) {
+        const uint4 r = __builtin_bit_cast(uint4, res);
+        c0[0] += __uint_as_float(r.x << 16); c0[1] += __uint_as_float(r.x & 0xFFFF0000u);
+        c0[2] += __uint_as_float(r.y << 16); c0[3] += __uint_as_float(r.y & 0xFFFF0000u);
+        c1[0] += __uint_as_float(r.z << 16); c1[1] += __uint_as_float(r.z & 0xFFFF0000u);
+        c1[2] += __uint_as_float(r.w << 16); c1[3] += __uint_as_float(r.w & 0xFFFF0000u);
     }
+    const uint4 o = make_uint4(relu_bf16x2(c0[0], c0[1]) & keep, relu_bf16x2(c0[2], c0[3]) & keep,
+                               relu_bf16x2(c1[0], c1[1]) & keep, relu_bf16x2(c1[2], c1[3]) & keep);
+    return __builtin_bit_cast(bf16x8, o);
 }
 
-// fragments of one row of taps (3 taps x 2 channel halves) for a tile.  `base` points 9 positions
-// before the tile's own position, so every tap is a non-negative immediate offset of the ds_read.
-__device__ __forceinline__ void load_taps(bf16x8 (&f)[6], const uint8_t* base, int row) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int d = (row * 8 + i) * PSTRIDE;
-        f[2 * i] = *reinterpret_cast<const bf16x8*>(base + d);
-        f[2 * i + 1] = *reinterpret_cast<const bf16x8*>(base + d + 32);
-    }
-}
-
-// One 3x3 conv over the wave's own two boards (3 tiles of 32 positions; 2 tiles when only the first
-// board holds a leaf): src -> dst (+ residual
-// read from dst when RES).  A wave's tiles only ever read positions of its own boards and the
-// never-written zero rows, so the tower needs no workgroup barrier: LDS operations of one wave
-// complete in issue order.  Loads run one row of taps ahead of the MFMAs that consume them.
+// One 3x3 conv of the task: in -> out (+ residual taken from out's old contents when RES; in and out are
+// different tensors).  wl = this conv's 18 weight fragments in LDS, bias = its 32 floats in LDS.
+// Taps are visited column by column of the window (centre column first, so the first MFMA of every
+// accumulator is the centre tap, whose C operand is the bias); the shifted fragments of a window column are
+// formed once and serve its three taps.
 template <bool RES>
-__device__ __forceinline__ void conv3x3(const Weights& w, const uint8_t* src, uint8_t* dst, uint8_t* dump,
-                                        const float* bias, int wave, int lane, bool two) {
-    const int h = lane >> 5;
-    int posb[TILES_PER_WAVE];
-    bool keep[TILES_PER_WAVE];
-    const uint8_t* base[TILES_PER_WAVE];
+__device__ __forceinline__ void conv3x3(const uint8_t* wl, const float* bias, const Act& in, Act& out, int lane,
+                                        uint32_t keep) {
+    const int q = lane >> 4;
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + 8 * q);
+    const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + 8 * q + 4);
+    const bf16x8* wf = reinterpret_cast<const bf16x8*>(wl) + lane;
+    f32x4 acc[ROWS][2];
 #pragma unroll
-    for (int t = 0; t < TILES_PER_WAVE; ++t) {
-        const int R = (wave * TILES_PER_WAVE + t) * 32 + (lane & 31);
-        const int b = R / 48, o = R - b * 48;
-        posb[t] = board_off(b, o);
-        keep[t] = (o & 7) != 7;
-        base[t] = src + posb[t] + (h * 16 - 9 * PSTRIDE);
-    }
-    // The epilogue of tile t-1 (vector ALU and LDS stores) is placed after the first MFMAs of tile t,
-    // which need nothing from it, so it runs while the matrix pipe works; only the last tile's
-    // epilogue stands alone.  (dst is never the source of this conv, so the early MFMAs of tile t do
-    // not read what tile t-1 still has to store.)
-    bf16x8 fa[6], fb[6];
-    f32x16 prev;
-    load_taps(fa, base[0], 0);
+    for (int kxi = 0; kxi < 3; ++kxi) {
+        const int kx = kxi == 0 ? 1 : (kxi == 1 ? 0 : 2);
+        // nothing of the next window column (its six weight fragments, its shifted rows) is started before
+        // this one is done: hoisted, they would not fit in the register file
+        if (kxi) __builtin_amdgcn_sched_barrier(0);
+        bf16x8 s[ROWS];
 #pragma unroll
-    for (int t = 0; t < TILES_PER_WAVE; ++t) {
-        if (t == 2 && !two) break;                 // a single board ends inside the second tile
-        f32x16 acc = bias_acc(bias, h);
-        load_taps(fb, base[t], 1);
+        for (int y = 0; y < ROWS; ++y)
+            s[y] = kx == 1 ? in.t[y] : (kx == 0 ? shift_cell<true>(in.t[y]) : shift_cell<false>(in.t[y]));
 #pragma unroll
-        for (int i = 0; i < 6; ++i) acc = MFMA(w.f[i], fa[i], acc);
-        // the zero cell that closes each row is computed like a cell; its result goes to a dump row
-        if (t > 0) store_tile<RES>(prev, (keep[t - 1] ? dst + posb[t - 1] : dump) + h * 8);
-        load_taps(fa, base[t], 2);
+        for (int kyi = 0; kyi < 3; ++kyi) {
+            const int ky = kyi == 0 ? 1 : (kyi == 1 ? 0 : 2);
+            const int tap = ky * 3 + kx;
+            const bf16x8 a0 = wf[(tap * 2) * 64], a1 = wf[(tap * 2 + 1) * 64];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) acc = MFMA(w.f[6 + i], fb[i], acc);
-        if (t + 1 < TILES_PER_WAVE) load_taps(fb, base[t + 1], 0);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) acc = MFMA(w.f[12 + i], fa[i], acc);
-        prev = acc;
-        if (t + 1 < TILES_PER_WAVE) {
-#pragma unroll
-            for (int i = 0; i < 6; ++i) fa[i] = fb[i];
+            for (int y = 0; y < ROWS; ++y) {
+                const int yy = y + ky - 1;                   // input row of this tap
+                if (yy < 0 || yy >= ROWS) continue;
+                if (kxi == 0 && kyi == 0) {
+                    acc[y][0] = MFMA16(a0, s[yy], b0);
+                    acc[y][1] = MFMA16(a1, s[yy], b1);
+                } else {
+                    acc[y][0] = MFMA16(a0, s[yy], acc[y][0]);
+                    acc[y][1] = MFMA16(a1, s[yy], acc[y][1]);
+                }
+            }
         }
     }
-    const int tl = two ? 2 : 1;
-    store_tile<RES>(prev, (keep[tl] ? dst + posb[tl] : dump) + h * 8);
+#pragma unroll
+    for (int y = 0; y < ROWS; ++y) out.t[y] = finish_row<RES>(acc[y][0], acc[y][1], out.t[y], keep);
 }
 
-// stem conv 2 -> C straight from bitboards: B[k][pos], k = tap*2 + plane (18 of 32 used)
-__device__ __forceinline__ void stem(const uint8_t* blob, const uint64_t* leaf_bb, const int* games, uint8_t* dst,
-                                     const float* bias, int wave, int lane, int ntiles) {
-    const int h = lane >> 5;
+// stem conv 2 -> C straight from the bitboards: the B fragment of row y holds k = tap*2 + plane (18 of 32
+// used) as bf16 1.0 / 0.0, built per lane from the 3x3 window around its cell
+__device__ __forceinline__ void stem(const uint8_t* blob, const uint64_t* leaf_bb, const int* games, Act& X,
+                                     const float* bias, int lane, uint32_t keep) {
+    const int p = lane & 15, q = lane >> 4;
+    const int x = (p & 7) == 7 ? 0 : (p & 7);                    // pad lanes compute a cell's window, then drop it
     const bf16x8 a0 = frag_ptr(blob, OFF_SF, lane)[0], a1 = frag_ptr(blob, OFF_SF, lane)[64];
-    // both boards' bitboards are requested before the first tile needs them: one memory latency per task
-    uint64_t bbs[4] = {0, 0, 0, 0};
+    const int g_first = games[0], g_second = games[1];
+    const int g = (p >> 3) ? g_second : g_first;
+    uint64_t bb[2] = {0, 0};
+    if (g >= 0) {
+        bb[0] = leaf_bb[2 * (size_t)g] << 8;
+        bb[1] = leaf_bb[2 * (size_t)g + 1] << 8;
+    }
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + 8 * q);
+    const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + 8 * q + 4);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-        if (games[i] >= 0) {
-            bbs[2 * i] = leaf_bb[2 * (size_t)games[i]] << 8;
-            bbs[2 * i + 1] = leaf_bb[2 * (size_t)games[i] + 1] << 8;
-        }
-#pragma unroll 1
-    for (int t = 0; t < ntiles; ++t) {
-        const int R = (wave * TILES_PER_WAVE + t) * 32 + (lane & 31);
-        const int b = R / 48, o = R - b * 48;
-        const int y = o >> 3, x = o & 7;
-        const bool second = b != 2 * wave;
-        const uint64_t bb[2] = {second ? bbs[2] : bbs[0], second ? bbs[3] : bbs[1]};
+    for (int y = 0; y < ROWS; ++y) {
         // after the shift, cell (xx, yy) with xx in -1..7, yy in -1..6 is bit (xx+1)*7 + yy + 1;
         // out-of-board neighbours fall on guard bits, which are zero.  Three rows of one window
         // column are three consecutive bits, so six 64-bit shifts fetch the whole 3x3x2 window;
@@ -204,25 +202,17 @@ __device__ __forceinline__ void stem(const uint8_t* blob, const uint64_t* leaf_b
                 const uint32_t c3 = (uint32_t)(bb[plane] >> ((x + tx) * 7 + y)) & 7u;       // rows ty = 0, 1, 2
                 m18 |= ((c3 * 0x421u) & 0x1041u) << (2 * tx + plane);                      // to bits 0, 6, 12
             }
-        // fragment s holds k = 16 s + 8 h + j, j = 0..7, as bf16 1.0 / 0.0: two per dword
-        const uint32_t k8 = (m18 >> (8 * h)) & 0xFFu, k2 = h ? 0u : (m18 >> 16) & 3u;
-        uint32_t d[5];
+        // this lane's eight k are bits 8q..8q+7 (nothing beyond bit 17): two per dword
+        const uint32_t k8 = (m18 >> (8 * q)) & 0xFFu;
+        uint32_t d[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t t2 = (k8 >> (2 * i)) & 3u;
             d[i] = (t2 & 1u) * 0x3F80u + (t2 >> 1) * 0x3F800000u;
         }
-        d[4] = (k2 & 1u) * 0x3F80u + (k2 >> 1) * 0x3F800000u;
-        bf16x8 f[2];
-        {
-            const uint4 f0 = make_uint4(d[0], d[1], d[2], d[3]), f1 = make_uint4(d[4], 0u, 0u, 0u);
-            f[0] = __builtin_bit_cast(bf16x8, f0);
-            f[1] = __builtin_bit_cast(bf16x8, f1);
-        }
-        f32x16 acc = bias_acc(bias, h);
-        acc = MFMA(a0, f[0], acc);
-        acc = MFMA(a1, f[1], acc);
-        if (x != 7) store_tile<false>(acc, dst + board_off(b, o) + h * 8);
+        const bf16x8 f = __builtin_bit_cast(bf16x8, make_uint4(d[0], d[1], d[2], d[3]));
+        const f32x4 c0 = MFMA16(a0, f, b0), c1 = MFMA16(a1, f, b1);
+        X.t[y] = finish_row<false>(c0, c1, f, keep);
     }
 }
 
@@ -230,14 +220,12 @@ __device__ __forceinline__ void stem(const uint8_t* blob, const uint64_t* leaf_b
 // two entries, entry = leaf index + 1, 0 = none), `nrounds` rounds; the whole workgroup calls it
 // (it contains workgroup barriers).  Writes p_out[leaf][7] and v_out[leaf].
 __device__ __forceinline__ void net_rounds(const uint8_t* blob, int num_blocks, const uint64_t* leaf_bb,
-                                           float* p_out, float* v_out, const Weights& w1, const Weights& w2,
-                                           uint8_t* bufX, uint8_t* bufY, uint8_t* scr, int nrounds, int tid,
-                                           int wave, int lane) {
-    const int h = lane >> 5;
+                                           float* p_out, float* v_out, const uint8_t* wlds, uint8_t* scr,
+                                           int nrounds, int tid, int wave, int lane) {
     float* sbias = reinterpret_cast<float*>(scr + S_BIAS);
     int* tlist = reinterpret_cast<int*>(scr + S_TL);
     // ---- Rounds.  In a round every wave takes up to two tasks (two boards each) through stem, tower
-    // and the 1x1 head convs on its own -- its two boards of the LDS images, no workgroup barrier --
+    // and the 1x1 head convs on its own -- activations in registers, no workgroup barrier --
     // and leaves four boards of head planes in its scratch.  The fully connected heads then run once
     // for the whole workgroup: 8 waves x 4 boards are exactly the 32 columns of an MFMA, wave w owns
     // rows 32w..32w+31 of the value FC and waves 0, 1 the two row tiles of the policy FC, so each
@@ -252,7 +240,7 @@ __device__ __forceinline__ void net_rounds(const uint8_t* blob, int num_blocks, 
     int* hgl = reinterpret_cast<int*>(scr + S_HG);                 // leaf of each of the 32 head columns
     float* lg = reinterpret_cast<float*>(scr + S_PW);              // [32 boards][64] logits, over the planes
     float* vpart = reinterpret_cast<float*>(scr + S_PW + 32 * 64 * 4);   // [8 waves][32 boards] value partial sums
-    uint8_t* dump = scr + S_DUMP + wave * 64;  // where results for the rows' zero cells go (never read back)
+    const uint32_t keep = (lane & 7) == 7 ? 0u : 0xFFFFFFFFu;      // pad cell of each board row stays zero
     for (int round = 0; round < nrounds; ++round) {
         int hg0 = -1, hg1 = -1, hg2 = -1, hg3 = -1;
 #pragma unroll 1
@@ -261,37 +249,30 @@ __device__ __forceinline__ void net_rounds(const uint8_t* blob, int num_blocks, 
             const int games[2] = {mylist[2 * iter] - 1, mylist[2 * iter + 1] - 1};
             if (games[0] < 0) break;
             if (half) { hg2 = games[0]; hg3 = games[1]; } else { hg0 = games[0]; hg1 = games[1]; }
-            const bool two = games[1] >= 0;
-            const int ntiles = two ? TILES_PER_WAVE : 2;
             const uint8_t* sblob = blob;
             asm volatile("" : "+s"(sblob));
-            stem(sblob, leaf_bb, games, bufY, sbias, wave, lane, ntiles);
+            Act X, Y;
+            stem(sblob, leaf_bb, games, X, sbias, lane, keep);
+#pragma unroll 1
             for (int blk = 0; blk < num_blocks; ++blk) {
-                conv3x3<false>(w1, bufY, bufX, dump, sbias + 32, wave, lane, two);
-                conv3x3<true>(w2, bufX, bufY, dump, sbias + 64, wave, lane, two);
+                conv3x3<false>(wlds, sbias + 32, X, Y, lane, keep);
+                conv3x3<true>(wlds + W_BYTES / 2, sbias + 64, Y, X, lane, keep);
             }
-            // 1x1 head convs as one 2-step MFMA: rows 0,1 = policy planes, row 2 = value plane.  (Head
-            // weights are fetched where they are used: hoisted above the loop they would be spilled,
-            // the tower owns the register file; the empty asm keeps the loads below this point.)
+            // 1x1 head convs as one MFMA per row: rows 0,1 of D = policy planes, row 2 = value plane, which
+            // land in the lanes q = 0 (registers 0..2) of each position
             const uint8_t* hblob = blob;
             asm volatile("" : "+s"(hblob));
-            const bf16x8 a0 = frag_ptr(hblob, OFF_HF, lane)[0], a1 = frag_ptr(hblob, OFF_HF, lane)[64];
-#pragma unroll 1
-            for (int t = 0; t < ntiles; ++t) {
-                const int R = (wave * TILES_PER_WAVE + t) * 32 + (lane & 31);
-                const int b = R / 48, o = R - b * 48;
-                const uint8_t* base = bufY + board_off(b, o) + h * 16;
-                f32x16 acc;
+            const bf16x8 ah = frag_ptr(hblob, OFF_HF, lane)[0];
+            const int p = lane & 15, x = p & 7, bl = (p >> 3) + 2 * half;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-                acc = MFMA(a0, *reinterpret_cast<const bf16x8*>(base), acc);
-                acc = MFMA(a1, *reinterpret_cast<const bf16x8*>(base + 32), acc);
-                const int y = o >> 3, x = o & 7, bl = b - 2 * wave + 2 * half;
-                if (h == 0 && x != 7) {
+            for (int y = 0; y < ROWS; ++y) {
+                const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
+                const f32x4 d = MFMA16(ah, X.t[y], z4);
+                if (lane < 16 && x != 7) {
                     const int cell = y * 7 + x;
-                    hp[bl * 96 + cell] = (__bf16)fmaxf(acc[0] + sbias[96], 0.0f);
-                    hp[bl * 96 + 42 + cell] = (__bf16)fmaxf(acc[1] + sbias[97], 0.0f);
-                    hv[bl * 48 + cell] = (__bf16)fmaxf(acc[2] + sbias[98], 0.0f);
+                    hp[bl * 96 + cell] = (__bf16)fmaxf(d[0] + sbias[96], 0.0f);
+                    hp[bl * 96 + 42 + cell] = (__bf16)fmaxf(d[1] + sbias[97], 0.0f);
+                    hv[bl * 48 + cell] = (__bf16)fmaxf(d[2] + sbias[98], 0.0f);
                 }
             }
         }

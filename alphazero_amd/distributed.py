@@ -62,7 +62,13 @@ def broadcast_packed(net, version, src=0, group=None):
     hdr = net.wire[:16].view(torch.int64)
     if dist.get_rank(group) == src:
         hdr.copy_(torch.tensor([int(version), int(net.num_blocks)], dtype=torch.int64))
-    dist.broadcast(net.wire, src, group=group)
+    if net.wire.is_cuda and dist.get_backend(group) == 'gloo':
+        # CPU-only rehearsals of the multi-rank path: gloo moves host memory, so stage through it
+        staged = net.wire.cpu()
+        dist.broadcast(staged, src, group=group)
+        net.wire.copy_(staged)
+    else:
+        dist.broadcast(net.wire, src, group=group)
     version, blocks = hdr.tolist()
     net.num_blocks = int(blocks)
     return int(version)

@@ -47,7 +47,7 @@ _FRAG_INDEX = {}
 
 
 def _frag_index(ksteps, device):
-    """Flat gather index of MFMA A fragments [ksteps][64][8] into a row-major [32][16*ksteps]
+    """Flat gather index of 32x32x16 MFMA A fragments [ksteps][64][8] into a row-major [32][16*ksteps]
     matrix: element j of lane l in k-step s is Wt[row = l & 31][k = 16*s + 8*(l >> 5) + j]."""
     key = (ksteps, str(device))
     if key not in _FRAG_INDEX:
@@ -60,7 +60,7 @@ def _frag_index(ksteps, device):
 
 
 def _gemm_frags(mat, ksteps):
-    """Dense matrix [rows <= 32][K <= 16*ksteps] -> bf16 fragment bytes (uint8 tensor)."""
+    """Dense matrix [rows <= 32][K <= 16*ksteps] -> bf16 fragment bytes (uint8 tensor), 32x32x16 MFMA."""
     rows, K = mat.shape
     pad = torch.zeros(32, 16 * ksteps, dtype=torch.float64, device=mat.device)
     pad[:rows, :K] = mat
@@ -68,12 +68,44 @@ def _gemm_frags(mat, ksteps):
     return fr.float().to(torch.bfloat16).contiguous().view(torch.uint8)
 
 
-def _conv_matrix(w):
-    """Folded 3x3 conv weight [co][ci][3][3] -> [co][9*32] with k = tap*32 + ci."""
+def _frag16_index(device):
+    """Gather index of ONE 16x16x32 MFMA A fragment [64 lanes][8] into a row-major [16][32] matrix:
+    element j of lane l is Wt[row = l & 15][k = 8*(l >> 4) + j]."""
+    key = ('16', str(device))
+    if key not in _FRAG_INDEX:
+        lane = torch.arange(64).view(-1, 1)
+        j = torch.arange(8).view(1, -1)
+        _FRAG_INDEX[key] = ((lane & 15) * 32 + 8 * (lane >> 4) + j).reshape(-1).to(device)
+    return _FRAG_INDEX[key]
+
+
+def _half_rows(device):
+    """Output channel computed by row r of MFMA half h in the trunk: 8*(r // 4) + 4*h + r % 4, so that the
+    MFMA result lands in the lanes' own B-fragment layout (csrc/az_net_dev.h).  int64 [2][16]."""
+    r = torch.arange(16, device=device)
+    return torch.stack([8 * (r // 4) + 4 * h + r % 4 for h in range(2)])
+
+
+def _frags16(mat):
+    """[..., 16 rows, 32 k] float64 -> bf16 fragment bytes [..., 64, 8] (uint8 tensor)."""
+    lead = mat.shape[:-2]
+    flat = mat.reshape(-1, 16 * 32)[:, _frag16_index(mat.device)]
+    return flat.reshape(*lead, 64 * 8).float().to(torch.bfloat16).contiguous().view(torch.uint8).reshape(-1)
+
+
+def _trunk_frags(w32):
+    """[..., 32 out channels (zero padded), 32 k] -> fragments [..., 2 halves, 64, 8]: the rows of half h are the
+    output channels _half_rows()[h]."""
+    rows = _half_rows(w32.device)                                   # [2][16]
+    return _frags16(w32[..., rows, :])                              # [..., 2, 16, 32]
+
+
+def _conv_taps(w):
+    """Folded 3x3 conv weight [co][ci][3][3] -> [9 taps][32][32] (tap = ky*3 + kx, zero padded)."""
     co, ci = w.shape[:2]
-    mat = torch.zeros(co, 9, 32, dtype=torch.float64, device=w.device)
-    mat[:, :, :ci] = w.permute(0, 2, 3, 1).reshape(co, 9, ci)
-    return mat.reshape(co, 288)
+    mat = torch.zeros(9, 32, 32, dtype=torch.float64, device=w.device)
+    mat[:, :co, :ci] = w.permute(2, 3, 0, 1).reshape(9, co, ci)
+    return mat
 
 
 def _f32_bytes(t, pad_to=None):
@@ -95,26 +127,28 @@ def pack_c4_blob(model):
     parts = []
     with torch.no_grad():
         bias = torch.zeros(3, 32, dtype=torch.float64, device=dev)
-        # stem: K index = tap*2 + plane
+        # stem: one k-step, K index = tap*2 + plane (18 of 32 used)
         w, b = _fold_bn(model._cbr[0].weight, model._cbr[1])
-        parts.append(_gemm_frags(w.permute(0, 2, 3, 1).reshape(C_, 18), 2))
+        stem = torch.zeros(32, 32, dtype=torch.float64, device=dev)
+        stem[:C_, :18] = w.permute(0, 2, 3, 1).reshape(C_, 18)
+        parts.append(_trunk_frags(stem))
         bias[0, :C_] = b
         if len(model._tower):
             blk = model._tower[0]
             for i, (cv, bn) in enumerate(((blk._c1, blk._bn1), (blk._c2, blk._bn2))):
                 w, b = _fold_bn(cv.weight, bn)
-                parts.append(_gemm_frags(_conv_matrix(w), 18))
+                parts.append(_trunk_frags(_conv_taps(w)))           # [9 taps][2 halves][64][8]
                 bias[1 + i, :C_] = b
         else:
             parts.append(torch.zeros(2 * 18 * 1024, dtype=torch.uint8, device=dev))
-        # heads: 1x1 convs -> rows 0,1 (policy planes) and 2 (value plane) of one [32][32] matrix
+        # heads: 1x1 convs -> rows 0,1 (policy planes) and 2 (value plane) of one [16][32] matrix
         ph, vh = model._policy_head, model._value_head
         wpol, bpol = _fold_bn(ph._cbr[0].weight, ph._cbr[1], ph._cbr[0].bias)
         wval, bval = _fold_bn(vh._cbr[0].weight, vh._cbr[1])
-        mat = torch.zeros(3, 32, dtype=torch.float64, device=dev)
+        mat = torch.zeros(16, 32, dtype=torch.float64, device=dev)
         mat[0:2, :C_] = wpol[:, :, 0, 0]
         mat[2, :C_] = wval[0, :, 0, 0]
-        parts.append(_gemm_frags(mat, 2))
+        parts.append(_frags16(mat))
         w1 = vh._fc[0].weight.double()                          # value FC1 [256][42]: 8 row tiles x 3 k-steps
         for t in range(8):
             parts.append(_gemm_frags(w1[32 * t:32 * t + 32], 3))

@@ -117,7 +117,7 @@ def test_bench_starts_two_ranks_by_itself():
     env.pop('WORLD_SIZE', None)
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--games', '256', '--sims', '32',
            '--mix-moves', '30', '--preroll', '2', '--steps', '3', '--warmup', '1', '--no-cpu-baseline']
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=150)
     assert res.returncode == 0, res.stderr[-2000:]
     line = [l for l in res.stdout.splitlines() if l.startswith('{')][-1]
     out = json.loads(line)
