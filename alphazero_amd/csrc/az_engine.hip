@@ -639,7 +639,7 @@ __device__ __forceinline__ void backup_g(uint4* pool, int depth, const uint32_t*
 template <class GM, int GS, bool DO_EXPAND, bool DO_SELECT, bool PATH_IN_SLOT = false>
 __device__ __forceinline__ void sim_step_game(const Dev& E, const float* p, const float* v, uint64_t* leaf_bb,
                                               int32_t* leaf_info, int g, int lane, int sub, Slot* s, uint4* pool,
-                                              uint32_t* path, int wave_id) {
+                                              uint32_t* path, int wave_id, uint64_t* lds_leaf = nullptr) {
     using G_ = Grp<GS>;
     constexpr int AS = GM::A + 1;
     const uint4* sh = reinterpret_cast<const uint4*>(s);
@@ -756,6 +756,7 @@ __device__ __forceinline__ void sim_step_game(const Dev& E, const float* p, cons
         if (sub == 0) {
             leaf_bb[2 * (size_t)g] = nx; leaf_bb[2 * (size_t)g + 1] = pv;
             leaf_info[g] = kind | (nm << 8) | ((int)GM::legal(nx, pv) << 16);
+            if (lds_leaf) { lds_leaf[0] = nx; lds_leaf[1] = pv; }      // a network in the same launch reads it here
         }
     }
     if (sub == 0) {
@@ -829,7 +830,8 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
             Slot* s = E.slots + g;
             uint4* pool = E.pool + (size_t)g * E.cap * (GameC4::A + 1);
             sim_step_game<GameC4, GS, decltype(tag_expand)::value, decltype(tag_select)::value, true>(
-                E, p, v, leaf_bb, leaf_info, g, ln, sub, s, pool, s->path, wave_id);
+                E, p, v, leaf_bb, leaf_info, g, ln, sub, s, pool, s->path, wave_id,
+                reinterpret_cast<uint64_t*>(scr + S_LBB) + 2 * gl);
         }
     };
     using T_ = std::true_type;
@@ -878,7 +880,7 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
         __syncthreads();
         const int nrounds = wtot[0];
         TICK(t_list);
-        net_rounds(blob, num_blocks, leaf_bb, p, v, wlds, scr, nrounds, tid, wave, lane);
+        net_rounds<true>(blob, num_blocks, leaf_bb, (int)blockIdx.x * gpw, p, v, wlds, scr, nrounds, tid, wave, lane);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");        // (p, v) written by the head phase
         __syncthreads();
         TICK(t_net);
@@ -886,6 +888,7 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
         else search(T_{}, F_{});
     }
 #ifdef AZ_EXP_TIMING
+    net_dbg_flush(scr, wave, lane);
     if (tid == 0) {
         unsigned long long* dbg = reinterpret_cast<unsigned long long*>(E.ring_count + 16);
         atomicAdd(dbg + 0, (unsigned long long)t_tree);
@@ -1359,10 +1362,14 @@ int az_sim_step(az_engine* e, float* p, float* v, uint64_t* leaf_bb, int32_t* le
 }
 
 #ifdef AZ_EXP_TIMING
-int az_debug_counters(az_engine* e, unsigned long long* out4) {
+// out: 4 phase counters of k_c4_move_fused, then the 8 counters of the network phase (az_net_dev.h)
+int az_debug_counters(az_engine* e, unsigned long long* out12) {
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(out4, e->d.ring_count + 16, 32, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out12, e->d.ring_count + 16, 32, hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(e->d.ring_count + 16, 0, 32));
+    HIPCHK(hipMemcpyFromSymbol(out12 + 4, HIP_SYMBOL(g_net_dbg), 64));
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_net_dbg), z, 64));
     return 0;
 }
 #endif

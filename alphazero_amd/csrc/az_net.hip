@@ -150,7 +150,7 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
         nrounds = (min(na, MAXIT * 2) + 3) >> 2;
     }
 
-    net_rounds(blob, num_blocks, leaf_bb, p_out, v_out, wlds, scr, nrounds, tid, wave, lane);
+    net_rounds<false>(blob, num_blocks, leaf_bb, 0, p_out, v_out, wlds, scr, nrounds, tid, wave, lane);
 }
 
 extern "C" {

@@ -35,7 +35,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define ROWS 6                    // board rows = tiles of a two-board task
 
 // LDS: tower weights, then scratch
-#define W_BYTES (2 * 18 * 1024)               // [2 convs][9 taps][2 halves][64 lanes][8] bf16
+#define W_BYTES (2 * 18 * 1024 + 2 * 1024)    // [2 convs][9 taps][2 halves][64 lanes][8] bf16, then the identity
+                                              // "tap" [2 halves][64][8] that adds the residual on the matrix cores
 #define S_BIAS 0                              // float[3][32] conv biases + head bias [4]
 #define S_B1 512                              // float[256] value FC1 bias
 #define S_W2 (S_B1 + 1024)                    // float[256] value FC2 weights
@@ -48,12 +49,19 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define S_TL (S_PW + 8 * PW_BYTES)            // int [8 waves][MAXIT][2] leaf index of each board
 #define S_WT (S_TL + 8 * MAXIT * 2 * 4)       // int [16] scan scratch
 #define S_HG (S_WT + 64)                      // int [32] leaf index of each head column
-#define S_BYTES (S_HG + 128)
+#define S_LBB (S_HG + 128)                    // uint64 [64][2] leaf positions of the workgroup's own games (kernels
+                                              // that produce the leaves themselves put them here)
+#ifdef AZ_EXP_TIMING
+#define S_DBG (S_LBB + 1024)                   // unsigned long long [8 waves][8] cycle counters (tuning builds only)
+#define S_BYTES (S_DBG + 512)
+#else
+#define S_BYTES (S_LBB + 1024)
+#endif
 #define LDS_BYTES (W_BYTES + S_BYTES)
 
 // blob layout (bytes); must match alphazero_amd/net.py
 #define OFF_SF 0                                   // stem      [2 halves][64][8] bf16 (16x16x32 A fragments)
-#define OFF_WF (OFF_SF + 2 * 1024)                 // c1, c2    [2][9 taps][2 halves][64][8] bf16
+#define OFF_WF (OFF_SF + 2 * 1024)                 // c1, c2    [2][9 taps][2 halves][64][8] bf16 + identity [2][64][8]
 #define OFF_HF (OFF_WF + W_BYTES)                  // 1x1 heads [64][8] bf16 (rows 0,1 policy planes, 2 value plane)
 #define OFF_F1 (OFF_HF + 1024)                     // value FC1 [8][3][64][8] bf16 (32x32x16 A fragments)
 #define OFF_PF (OFF_F1 + 8 * 3 * 1024)             // policy FC [2][6][64][8] bf16
@@ -93,8 +101,52 @@ __device__ __forceinline__ uint32_t relu_bf16x2(float a, float b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, y), z));
 }
 
-// activations of a two-board task: fragment y = row y of both boards, lane (p, q) = channels 8q..8q+7 of cell p
-struct Act { bf16x8 t[ROWS]; };
+__device__ __forceinline__ uint32_t bf16x2_of(float a, float b) {
+    const f32x2 f = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The trunk of one task (two boards), written as a software pipeline.  Register state:
+//   X[y]      bf16 fragment of row y of the block input (lane (p, q) = channels 8q..8q+7 of cell p)
+//   Y[y]      the same for the output of the block's first conv
+//   acc[y][h] the twelve independent accumulators of the conv in flight (h = channel half: 8q+4h..8q+4h+3)
+// A conv's epilogue (ReLU, bf16) is merged with the centre tap of the NEXT conv (which needs row y only): row
+// by row, finish row y, then issue its two centre MFMAs, so the vector work of row y+1 runs under the matrix
+// work of row y even when the wave is alone on its SIMD.  The residual connection is one more "tap" of the
+// block's second conv: an identity matrix times X on the matrix cores (exact: 1.0 x bf16 in an fp32
+// accumulator) instead of sixteen vector instructions per row.  Weight fragments are requested one tap ahead
+// of the MFMAs that use them and the lane-shifted rows of a window column are formed during the previous
+// column's taps; scheduling fences between taps keep the compiler from hoisting all requests (they would not
+// fit in the register file) or sinking them next to their use (their latency would be exposed).
+// The pad lane of each board row must read as zero to its neighbours: its bias is -1e30, which the ReLU
+// returns to zero, so no masking instruction is needed.
+// ---------------------------------------------------------------------------------------------------------
+#define PAD_BIAS (-1.0e30f)
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+
+struct Bias2 { f32x4 h0, h1; };
+__device__ __forceinline__ Bias2 lane_bias(const float* bias, int lane) {
+    const int q = lane >> 4;
+    Bias2 b;
+    b.h0 = *reinterpret_cast<const f32x4*>(bias + 8 * q);
+    b.h1 = *reinterpret_cast<const f32x4*>(bias + 8 * q + 4);
+    if ((lane & 7) == 7) {
+        const f32x4 pad = {PAD_BIAS, PAD_BIAS, PAD_BIAS, PAD_BIAS};
+        b.h0 = pad; b.h1 = pad;
+    }
+    return b;
+}
+
+struct WPair { bf16x8 a0, a1; };                             // the two channel halves of one tap's weights
+// CONV 0, 1: the block's convs; CONV 2 with KY = KX = 0: the identity
+template <int CONV, int KY, int KX>
+__device__ __forceinline__ WPair wload(const uint8_t* wlds, int lane) {
+    const bf16x8* wf = reinterpret_cast<const bf16x8*>(wlds) + ((CONV * 9 + KY * 3 + KX) * 2) * 64 + lane;
+    WPair w;
+    w.a0 = wf[0]; w.a1 = wf[64];
+    return w;
+}
 
 // the row's fragment as seen one cell to the left (LEFT: lane p reads lane p - 1) or to the right, zero at
 // the ends of the 16-lane row
@@ -110,96 +162,103 @@ __device__ __forceinline__ bf16x8 shift_cell(const bf16x8& v) {
     return __builtin_bit_cast(bf16x8, r);
 }
 
-// (+ residual) -> ReLU -> bf16, the two accumulator halves of one row -> its fragment; `keep` is all ones on
-// cell lanes and zero on the pad lanes
-template <bool RES>
-__device__ __forceinline__ bf16x8 finish_row(f32x4 c0, f32x4 c1, const bf16x8& res, uint32_t keep) {
-    if (RES) {
-        const uint4 r = __builtin_bit_cast(uint4, res);
-        c0[0] += __uint_as_float(r.x << 16); c0[1] += __uint_as_float(r.x & 0xFFFF0000u);
-        c0[2] += __uint_as_float(r.y << 16); c0[3] += __uint_as_float(r.y & 0xFFFF0000u);
-        c1[0] += __uint_as_float(r.z << 16); c1[1] += __uint_as_float(r.z & 0xFFFF0000u);
-        c1[2] += __uint_as_float(r.w << 16); c1[3] += __uint_as_float(r.w & 0xFFFF0000u);
+// the MFMAs of one tap: output row y takes input row y + KY - 1 (rows -1 and 6 do not exist)
+template <int KY>
+__device__ __forceinline__ void tap_rows(f32x4 (&acc)[ROWS][2], const bf16x8 (&s)[ROWS], const WPair& w) {
+#pragma unroll
+    for (int y = 0; y < ROWS; ++y) {
+        const int yy = y + KY - 1;
+        if (yy < 0 || yy >= ROWS) continue;
+        acc[y][0] = MFMA16(w.a0, s[yy], acc[y][0]);
+        acc[y][1] = MFMA16(w.a1, s[yy], acc[y][1]);
     }
-    const uint4 o = make_uint4(relu_bf16x2(c0[0], c0[1]) & keep, relu_bf16x2(c0[2], c0[3]) & keep,
-                               relu_bf16x2(c1[0], c1[1]) & keep, relu_bf16x2(c1[2], c1[3]) & keep);
-    return __builtin_bit_cast(bf16x8, o);
 }
 
-// One 3x3 conv of the task: in -> out (+ residual taken from out's old contents when RES; in and out are
-// different tensors).  wl = this conv's 18 weight fragments in LDS, bias = its 32 floats in LDS.
-// Taps are visited column by column of the window (centre column first, so the first MFMA of every
-// accumulator is the centre tap, whose C operand is the bias); the shifted fragments of a window column are
-// formed once and serve its three taps.
-template <bool RES>
-__device__ __forceinline__ void conv3x3(const uint8_t* wl, const float* bias, const Act& in, Act& out, int lane,
-                                        uint32_t keep) {
-    const int q = lane >> 4;
-    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + 8 * q);
-    const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + 8 * q + 4);
-    const bf16x8* wf = reinterpret_cast<const bf16x8*>(wl) + lane;
-    f32x4 acc[ROWS][2];
+// The eight taps around the centre of conv CONV over `in`, plus (RES) the identity tap over `res`.  On entry
+// w = weights of tap (0,1) of CONV, on exit w = weights of the centre tap of conv NEXT.
+template <int CONV, int NEXT, bool RES>
+__device__ __forceinline__ void conv_rest(const uint8_t* wlds, const bf16x8 (&in)[ROWS], const bf16x8 (&res)[ROWS],
+                                          f32x4 (&acc)[ROWS][2], WPair& w, int lane) {
+    WPair n;
+    bf16x8 sl[ROWS], sr[ROWS];
+    // centre column of the window; meanwhile the rows as seen from the right-hand neighbour (window column 0)
+    n = wload<CONV, 2, 1>(wlds, lane); tap_rows<0>(acc, in, w);
 #pragma unroll
-    for (int kxi = 0; kxi < 3; ++kxi) {
-        const int kx = kxi == 0 ? 1 : (kxi == 1 ? 0 : 2);
-        // nothing of the next window column (its six weight fragments, its shifted rows) is started before
-        // this one is done: hoisted, they would not fit in the register file
-        if (kxi) __builtin_amdgcn_sched_barrier(0);
-        bf16x8 s[ROWS];
+    for (int y = 0; y < 3; ++y) sl[y] = shift_cell<true>(in[y]);
+    w = n; FENCE();
+    n = RES ? wload<2, 0, 0>(wlds, lane) : wload<CONV, 1, 0>(wlds, lane); tap_rows<2>(acc, in, w);
 #pragma unroll
-        for (int y = 0; y < ROWS; ++y)
-            s[y] = kx == 1 ? in.t[y] : (kx == 0 ? shift_cell<true>(in.t[y]) : shift_cell<false>(in.t[y]));
+    for (int y = 3; y < ROWS; ++y) sl[y] = shift_cell<true>(in[y]);
+    w = n; FENCE();
+    if (RES) {
+        n = wload<CONV, 1, 0>(wlds, lane); tap_rows<1>(acc, res, w); w = n; FENCE();
+    }
+    // window column 0; meanwhile the rows as seen from the left-hand neighbour (window column 2)
+    n = wload<CONV, 0, 0>(wlds, lane); tap_rows<1>(acc, sl, w);
+    sr[0] = shift_cell<false>(in[0]); sr[1] = shift_cell<false>(in[1]);
+    w = n; FENCE();
+    n = wload<CONV, 2, 0>(wlds, lane); tap_rows<0>(acc, sl, w);
+    sr[2] = shift_cell<false>(in[2]); sr[3] = shift_cell<false>(in[3]);
+    w = n; FENCE();
+    n = wload<CONV, 1, 2>(wlds, lane); tap_rows<2>(acc, sl, w);
+    sr[4] = shift_cell<false>(in[4]); sr[5] = shift_cell<false>(in[5]);
+    w = n; FENCE();
+    // window column 2
+    n = wload<CONV, 0, 2>(wlds, lane); tap_rows<1>(acc, sr, w); w = n; FENCE();
+    n = wload<CONV, 2, 2>(wlds, lane); tap_rows<0>(acc, sr, w); w = n; FENCE();
+    n = wload<NEXT, 1, 1>(wlds, lane); tap_rows<2>(acc, sr, w); w = n; FENCE();
+}
+
+// Between two convs: acc -> out (ReLU, bf16) and, when CENTRE, the centre tap of the next conv with its bias as
+// the C operand.  On entry w = centre weights of conv NEXT, on exit w = weights of its tap (0,1).
+template <int NEXT, bool CENTRE>
+__device__ __forceinline__ void between_convs(const uint8_t* wlds, f32x4 (&acc)[ROWS][2], bf16x8 (&out)[ROWS],
+                                              const Bias2& bias, WPair& w, int lane) {
+    const WPair n = wload<NEXT, 0, 1>(wlds, lane);
 #pragma unroll
-        for (int kyi = 0; kyi < 3; ++kyi) {
-            const int ky = kyi == 0 ? 1 : (kyi == 1 ? 0 : 2);
-            const int tap = ky * 3 + kx;
-            const bf16x8 a0 = wf[(tap * 2) * 64], a1 = wf[(tap * 2 + 1) * 64];
-#pragma unroll
-            for (int y = 0; y < ROWS; ++y) {
-                const int yy = y + ky - 1;                   // input row of this tap
-                if (yy < 0 || yy >= ROWS) continue;
-                if (kxi == 0 && kyi == 0) {
-                    acc[y][0] = MFMA16(a0, s[yy], b0);
-                    acc[y][1] = MFMA16(a1, s[yy], b1);
-                } else {
-                    acc[y][0] = MFMA16(a0, s[yy], acc[y][0]);
-                    acc[y][1] = MFMA16(a1, s[yy], acc[y][1]);
-                }
-            }
+    for (int y = 0; y < ROWS; ++y) {
+        const f32x4 c0 = acc[y][0], c1 = acc[y][1];
+        out[y] = __builtin_bit_cast(bf16x8, make_uint4(relu_bf16x2(c0[0], c0[1]), relu_bf16x2(c0[2], c0[3]),
+                                                       relu_bf16x2(c1[0], c1[1]), relu_bf16x2(c1[2], c1[3])));
+        if (CENTRE) {
+            acc[y][0] = MFMA16(w.a0, out[y], bias.h0);
+            acc[y][1] = MFMA16(w.a1, out[y], bias.h1);
+            FENCE();                                         // row by row: vector work of row y+1 under these MFMAs
         }
     }
-#pragma unroll
-    for (int y = 0; y < ROWS; ++y) out.t[y] = finish_row<RES>(acc[y][0], acc[y][1], out.t[y], keep);
+    w = n;
+    FENCE();
 }
 
 // stem conv 2 -> C straight from the bitboards: the B fragment of row y holds k = tap*2 + plane (18 of 32
-// used) as bf16 1.0 / 0.0, built per lane from the 3x3 window around its cell
-__device__ __forceinline__ void stem(const uint8_t* blob, const uint64_t* leaf_bb, const int* games, Act& X,
-                                     const float* bias, int lane, uint32_t keep) {
+// used) as bf16 1.0 / 0.0, built per lane from the 3x3 window around its cell; leaves the raw accumulators
+__device__ __forceinline__ void stem(const uint8_t* blob, const uint64_t* pos /* this lane's board, or null */,
+                                     f32x4 (&acc)[ROWS][2], const Bias2& b0, int lane) {
     const int p = lane & 15, q = lane >> 4;
     const int x = (p & 7) == 7 ? 0 : (p & 7);                    // pad lanes compute a cell's window, then drop it
     const bf16x8 a0 = frag_ptr(blob, OFF_SF, lane)[0], a1 = frag_ptr(blob, OFF_SF, lane)[64];
-    const int g_first = games[0], g_second = games[1];
-    const int g = (p >> 3) ? g_second : g_first;
-    uint64_t bb[2] = {0, 0};
-    if (g >= 0) {
-        bb[0] = leaf_bb[2 * (size_t)g] << 8;
-        bb[1] = leaf_bb[2 * (size_t)g + 1] << 8;
+    // After a shift by 8, cell (xx, yy) with xx in -1..7, yy in -1..6 is bit (xx+1)*7 + yy + 1; out-of-board
+    // neighbours fall on guard bits, which are zero.  The three window columns of this lane's cell are taken out
+    // once per task (nine bits each: rows -1..7), so the per-row work is 32-bit.
+    uint32_t col[2][3] = {{0, 0, 0}, {0, 0, 0}};
+    if (pos) {
+#pragma unroll
+        for (int plane = 0; plane < 2; ++plane) {
+            const uint64_t b = pos[plane] << 8;
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) col[plane][tx] = (uint32_t)(b >> ((x + tx) * 7)) & 0x1FFu;
+        }
     }
-    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + 8 * q);
-    const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + 8 * q + 4);
 #pragma unroll
     for (int y = 0; y < ROWS; ++y) {
-        // after the shift, cell (xx, yy) with xx in -1..7, yy in -1..6 is bit (xx+1)*7 + yy + 1;
-        // out-of-board neighbours fall on guard bits, which are zero.  Three rows of one window
-        // column are three consecutive bits, so six 64-bit shifts fetch the whole 3x3x2 window;
-        // m18 collects it as bit k = 2 * tap + plane, tap = 3 * row + column of the window.
+        // three rows of one window column are three consecutive bits; m18 collects the 3x3x2 window as
+        // bit k = 2 * tap + plane, tap = 3 * row + column of the window
         uint32_t m18 = 0;
 #pragma unroll
         for (int plane = 0; plane < 2; ++plane)
 #pragma unroll
             for (int tx = 0; tx < 3; ++tx) {
-                const uint32_t c3 = (uint32_t)(bb[plane] >> ((x + tx) * 7 + y)) & 7u;       // rows ty = 0, 1, 2
+                const uint32_t c3 = (col[plane][tx] >> y) & 7u;                            // rows ty = 0, 1, 2
                 m18 |= ((c3 * 0x421u) & 0x1041u) << (2 * tx + plane);                      // to bits 0, 6, 12
             }
         // this lane's eight k are bits 8q..8q+7 (nothing beyond bit 17): two per dword
@@ -211,17 +270,38 @@ __device__ __forceinline__ void stem(const uint8_t* blob, const uint64_t* leaf_b
             d[i] = (t2 & 1u) * 0x3F80u + (t2 >> 1) * 0x3F800000u;
         }
         const bf16x8 f = __builtin_bit_cast(bf16x8, make_uint4(d[0], d[1], d[2], d[3]));
-        const f32x4 c0 = MFMA16(a0, f, b0), c1 = MFMA16(a1, f, b1);
-        X.t[y] = finish_row<false>(c0, c1, f, keep);
+        acc[y][0] = MFMA16(a0, f, b0.h0);
+        acc[y][1] = MFMA16(a1, f, b0.h1);
     }
 }
+
+#ifdef AZ_EXP_TIMING     // tuning aid: shader cycles per part of the network phase, summed over waves
+// 0 stem+first centre, 1 tower, 2 head convs, 3 wait for the other waves, 4 fully connected heads + soft-max,
+// 5 tasks, 6 waves that had a task, 7 waves without one: their whole wait
+__device__ unsigned long long g_net_dbg[8];
+// accumulated per wave in LDS (scr + S_DBG), flushed to g_net_dbg once at the end of the kernel
+#define NTICK(i) do { const long long _t = clock64(); if (lane == 0) ndbg[i] += (unsigned long long)(_t - nt0); nt0 = _t; } while (0)
+#define NCOUNT(i) do { if (lane == 0) ndbg[i] += 1ull; } while (0)
+__device__ __forceinline__ void net_dbg_flush(uint8_t* scr, int wave, int lane) {
+    if (lane < 8) atomicAdd(&g_net_dbg[lane], reinterpret_cast<unsigned long long*>(scr + S_DBG)[wave * 8 + lane]);
+}
+#else
+#define NTICK(i) do { } while (0)
+#define NCOUNT(i) do { } while (0)
+#endif
 
 // The network for the leaves listed in the workgroup's task list (scr + S_TL: per wave MAXIT tasks of
 // two entries, entry = leaf index + 1, 0 = none), `nrounds` rounds; the whole workgroup calls it
 // (it contains workgroup barriers).  Writes p_out[leaf][7] and v_out[leaf].
-__device__ __forceinline__ void net_rounds(const uint8_t* blob, int num_blocks, const uint64_t* leaf_bb,
+// LDS_BB: the position of leaf g is read from the LDS table scr + S_LBB, entry g - g_base, instead of leaf_bb.
+template <bool LDS_BB>
+__device__ __forceinline__ void net_rounds(const uint8_t* blob, int num_blocks, const uint64_t* leaf_bb, int g_base,
                                            float* p_out, float* v_out, const uint8_t* wlds, uint8_t* scr,
                                            int nrounds, int tid, int wave, int lane) {
+    const uint64_t* lbb = reinterpret_cast<const uint64_t*>(scr + S_LBB);
+    auto position = [&](int g) -> const uint64_t* {
+        return LDS_BB ? lbb + 2 * (g - g_base) : leaf_bb + 2 * (size_t)g;
+    };
     float* sbias = reinterpret_cast<float*>(scr + S_BIAS);
     int* tlist = reinterpret_cast<int*>(scr + S_TL);
     // ---- Rounds.  In a round every wave takes up to two tasks (two boards each) through stem, tower
@@ -240,24 +320,46 @@ __device__ __forceinline__ void net_rounds(const uint8_t* blob, int num_blocks, 
     int* hgl = reinterpret_cast<int*>(scr + S_HG);                 // leaf of each of the 32 head columns
     float* lg = reinterpret_cast<float*>(scr + S_PW);              // [32 boards][64] logits, over the planes
     float* vpart = reinterpret_cast<float*>(scr + S_PW + 32 * 64 * 4);   // [8 waves][32 boards] value partial sums
-    const uint32_t keep = (lane & 7) == 7 ? 0u : 0xFFFFFFFFu;      // pad cell of each board row stays zero
     for (int round = 0; round < nrounds; ++round) {
         int hg0 = -1, hg1 = -1, hg2 = -1, hg3 = -1;
+#ifdef AZ_EXP_TIMING
+        unsigned long long* ndbg = reinterpret_cast<unsigned long long*>(scr + S_DBG) + wave * 8;
+        long long nt0 = clock64();
+        bool worked = false;
+#endif
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
             const int iter = 2 * round + half;
-            const int games[2] = {mylist[2 * iter] - 1, mylist[2 * iter + 1] - 1};
-            if (games[0] < 0) break;
-            if (half) { hg2 = games[0]; hg3 = games[1]; } else { hg0 = games[0]; hg1 = games[1]; }
+            const int g_first = mylist[2 * iter] - 1, g_second = mylist[2 * iter + 1] - 1;
+            if (g_first < 0) break;
+#ifdef AZ_EXP_TIMING
+            worked = true;
+            NCOUNT(5);
+#endif
+            if (half) { hg2 = g_first; hg3 = g_second; } else { hg0 = g_first; hg1 = g_second; }
             const uint8_t* sblob = blob;
             asm volatile("" : "+s"(sblob));
-            Act X, Y;
-            stem(sblob, leaf_bb, games, X, sbias, lane, keep);
+            bf16x8 X[ROWS], Y[ROWS];
+            f32x4 acc[ROWS][2];
+            const Bias2 b1 = lane_bias(sbias + 32, lane), b2 = lane_bias(sbias + 64, lane);
+            {
+                const Bias2 b0 = lane_bias(sbias, lane);
+                const int g_mine = (lane & 8) ? g_second : g_first;
+                stem(sblob, g_mine >= 0 ? position(g_mine) : nullptr, acc, b0, lane);
+            }
+            WPair w = wload<0, 1, 1>(wlds, lane);
+            if (num_blocks > 0) between_convs<0, true>(wlds, acc, X, b1, w, lane);
+            else between_convs<0, false>(wlds, acc, X, b1, w, lane);
+            NTICK(0);
 #pragma unroll 1
             for (int blk = 0; blk < num_blocks; ++blk) {
-                conv3x3<false>(wlds, sbias + 32, X, Y, lane, keep);
-                conv3x3<true>(wlds + W_BYTES / 2, sbias + 64, Y, X, lane, keep);
+                conv_rest<0, 1, false>(wlds, X, X, acc, w, lane);
+                between_convs<1, true>(wlds, acc, Y, b2, w, lane);
+                conv_rest<1, 0, true>(wlds, Y, X, acc, w, lane);
+                if (blk + 1 < num_blocks) between_convs<0, true>(wlds, acc, X, b1, w, lane);
+                else between_convs<0, false>(wlds, acc, X, b1, w, lane);
             }
+            NTICK(1);
             // 1x1 head convs as one MFMA per row: rows 0,1 of D = policy planes, row 2 = value plane, which
             // land in the lanes q = 0 (registers 0..2) of each position
             const uint8_t* hblob = blob;
@@ -267,7 +369,7 @@ __device__ __forceinline__ void net_rounds(const uint8_t* blob, int num_blocks, 
 #pragma unroll
             for (int y = 0; y < ROWS; ++y) {
                 const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
-                const f32x4 d = MFMA16(ah, X.t[y], z4);
+                const f32x4 d = MFMA16(ah, X[y], z4);
                 if (lane < 16 && x != 7) {
                     const int cell = y * 7 + x;
                     hp[bl * 96 + cell] = (__bf16)fmaxf(d[0] + sbias[96], 0.0f);
@@ -276,8 +378,14 @@ __device__ __forceinline__ void net_rounds(const uint8_t* blob, int num_blocks, 
                 }
             }
         }
+#ifdef AZ_EXP_TIMING
+        if (worked) { NTICK(2); NCOUNT(6); } else NCOUNT(7);
+#endif
         if (lane < 4) hgl[wave * 4 + lane] = lane == 0 ? hg0 : lane == 1 ? hg1 : lane == 2 ? hg2 : hg3;
         __syncthreads();                                   // every wave's planes are in place
+#ifdef AZ_EXP_TIMING
+        if (worked) NTICK(3); else NTICK(7);
+#endif
 
         const uint8_t* fblob = blob;
         asm volatile("" : "+s"(fblob));
@@ -339,7 +447,7 @@ __device__ __forceinline__ void net_rounds(const uint8_t* blob, int num_blocks, 
             const int b = ht >> 3, col = ht & 7;
             const int gidx = hgl[b];
             uint64_t occ = 0;
-            if (gidx >= 0) occ = leaf_bb[2 * (size_t)gidx] | leaf_bb[2 * (size_t)gidx + 1];
+            if (gidx >= 0) occ = position(gidx)[0] | position(gidx)[1];
             const int height = col < 7 ? __popcll((occ >> (7 * col)) & 0x3Full) : 6;
             const bool legal = col < 7 && height < 6;
             const float logit = legal ? lg[b * 64 + height * 7 + col] : -INFINITY;
@@ -357,6 +465,7 @@ __device__ __forceinline__ void net_rounds(const uint8_t* blob, int num_blocks, 
             for (int w = 0; w < 8; ++w) sv += vpart[w * 32 + b];
             if (gidx >= 0) v_out[gidx] = tanhf(sv + reinterpret_cast<const float*>(fblob + OFF_B2)[0]);
         }
+        NTICK(4);
         if (round + 1 < nrounds) {
             // the planes (and their k-padding) must read as zero again before the next round fills them
             __syncthreads();

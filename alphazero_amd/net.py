@@ -141,6 +141,8 @@ def pack_c4_blob(model):
                 bias[1 + i, :C_] = b
         else:
             parts.append(torch.zeros(2 * 18 * 1024, dtype=torch.uint8, device=dev))
+        # the residual connection as a "tap" of the second conv: identity over the 32 channels
+        parts.append(_trunk_frags(torch.eye(32, dtype=torch.float64, device=dev)))
         # heads: 1x1 convs -> rows 0,1 (policy planes) and 2 (value plane) of one [16][32] matrix
         ph, vh = model._policy_head, model._value_head
         wpol, bpol = _fold_bn(ph._cbr[0].weight, ph._cbr[1], ph._cbr[0].bias)

@@ -17,7 +17,7 @@ net = FusedC4Net.from_module(AlphaZeroC4(6, 32).eval().cuda(), 'cuda')
 for i in range(160):
     eng.begin_move_uniform(); eng.run_sims_uniform(S); eng.choose_and_advance()
     if i % 2: eng.drain_finished()
-out = (C.c_ulonglong * 4)()
+out = (C.c_ulonglong * 12)()
 for i in range(12):
     bb, info = eng.begin_move(); p, _ = net(bb, info); eng.apply_root(p)
     eng.lib.az_debug_counters(eng.h, out)
@@ -26,3 +26,8 @@ for i in range(12):
     eng.lib.az_debug_counters(eng.h, out)
     n = out[3]
     print(f'move {i}: per WG per sim, shader cycles: tree {out[0]/n/S:.0f}  list {out[1]/n/S:.0f}  net {out[2]/n/S:.0f}  (WGs {n})')
+    d = out[4:12]
+    tasks, busy, idle = max(d[5], 1), max(d[6], 1), max(d[7], 1)
+    print(f'   network phase, per wave with work: stem {d[0]/tasks:.0f}/task  tower {d[1]/tasks:.0f}/task  head convs {d[2]/busy:.0f}  '
+          f'wait {d[3]/busy:.0f}  fc+softmax {d[4]/(busy+idle):.0f};  tasks per WG-sim {tasks/n/S:.2f}, waves with work {busy/n/S:.2f}, '
+          f'idle waves wait {d[7]/idle:.0f}')
