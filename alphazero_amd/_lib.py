@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libazhip.so')
+# AZHIP_LIBRARY: another build of the same library (tuning builds with in-kernel timers); default: the in-tree one
+LIB_PATH = os.environ.get('AZHIP_LIBRARY') or os.path.join(HERE, 'libazhip.so')
 
 GAME_TTT, GAME_C4 = 0, 1
 MAX_ACTIONS, MAX_MOVES = 9, 42

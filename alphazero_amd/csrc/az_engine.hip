@@ -799,20 +799,21 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
     constexpr int GS = 8;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t* wlds = lds;
-    uint8_t* scr = lds + W_BYTES;
+    uint8_t* scr = lds + OFF_BIAS;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     {
         uint4* z = reinterpret_cast<uint4*>(scr);
         for (int i = tid; i < S_BYTES / 16; i += NTHREADS) z[i] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
-    if (tid < 100) reinterpret_cast<float*>(scr + S_BIAS)[tid] = reinterpret_cast<const float*>(blob + OFF_BIAS)[tid];
+    if (tid < 99) reinterpret_cast<float*>(scr + S_BIAS)[tid] = reinterpret_cast<const float*>(blob + OFF_BIAS)[tid];
+    if (tid == 99) reinterpret_cast<float*>(scr + S_BIAS)[99] = reinterpret_cast<const float*>(blob + OFF_B2)[0];
     if (tid < 256) {
         reinterpret_cast<float*>(scr + S_B1)[tid] = reinterpret_cast<const float*>(blob + OFF_B1)[tid];
         reinterpret_cast<float*>(scr + S_W2)[tid] = reinterpret_cast<const float*>(blob + OFF_W2)[tid];
     }
     if (tid < 64) reinterpret_cast<float*>(scr + S_BP)[tid] = reinterpret_cast<const float*>(blob + OFF_BP)[tid];
-    load_tower_weights(blob, wlds, tid);         // once per move; ordered before their first use by the barriers below
+    load_weights(blob, wlds, tid);         // once per move; ordered before their first use by the barriers below
 
     // search lanes: thread t serves game g_base + t / 8 (gpw <= 64 games per workgroup).  Everything a
     // search phase needs is re-derived from an opaque copy of the thread index at its start, so no

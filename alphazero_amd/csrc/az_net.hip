@@ -20,7 +20,7 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
              int grid_shift) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t* wlds = lds;                       // tower weights
-    uint8_t* scr = lds + W_BYTES;
+    uint8_t* scr = lds + OFF_BIAS;
     float* sbias = reinterpret_cast<float*>(scr + S_BIAS);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 
@@ -34,7 +34,8 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
     // then this thread's slice of leaf_info, and only then the workgroup's 36 KB of tower weights (loads
     // return in order, so whatever is waited for first must not queue behind the weights).
     float t_bias = 0.0f, t_b1 = 0.0f, t_w2 = 0.0f, t_bp = 0.0f;
-    if (tid < 100) t_bias = reinterpret_cast<const float*>(blob + OFF_BIAS)[tid];
+    if (tid < 99) t_bias = reinterpret_cast<const float*>(blob + OFF_BIAS)[tid];
+    if (tid == 99) t_bias = reinterpret_cast<const float*>(blob + OFF_B2)[0];      // value FC2 bias rides in the pad slot
     if (tid < 256) {
         t_b1 = reinterpret_cast<const float*>(blob + OFF_B1)[tid];
         t_w2 = reinterpret_cast<const float*>(blob + OFF_W2)[tid];
@@ -57,7 +58,7 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
     int4 kfirst[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) kfirst[q] = (leaf_info && 4 * q < per) ? load4(g0 + 4 * q) : make_int4(0, 0, 0, 0);
-    load_tower_weights(blob, wlds, tid);
+    load_weights(blob, wlds, tid);
     __syncthreads();
     if (tid < 100) sbias[tid] = t_bias;
     if (tid < 256) {

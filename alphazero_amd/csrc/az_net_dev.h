@@ -34,10 +34,10 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define NTHREADS 512
 #define ROWS 6                    // board rows = tiles of a two-board task
 
-// LDS: tower weights, then scratch
-#define W_BYTES (2 * 18 * 1024 + 2 * 1024)    // [2 convs][9 taps][2 halves][64 lanes][8] bf16, then the identity
+// LDS: every MFMA weight fragment of the blob (its first OFF_BIAS bytes, same offsets), then scratch
+#define W_BYTES (2 * 18 * 1024 + 2 * 1024)    // tower: [2 convs][9 taps][2 halves][64 lanes][8] bf16, then the identity
                                               // "tap" [2 halves][64][8] that adds the residual on the matrix cores
-#define S_BIAS 0                              // float[3][32] conv biases + head bias [4]
+#define S_BIAS 0                              // float[3][32] conv biases, head biases [3], value FC2 bias [1]
 #define S_B1 512                              // float[256] value FC1 bias
 #define S_W2 (S_B1 + 1024)                    // float[256] value FC2 weights
 #define S_BP (S_W2 + 1024)                    // float[64]  policy FC bias
@@ -57,7 +57,6 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #else
 #define S_BYTES (S_LBB + 1024)
 #endif
-#define LDS_BYTES (W_BYTES + S_BYTES)
 
 // blob layout (bytes); must match alphazero_amd/net.py
 #define OFF_SF 0                                   // stem      [2 halves][64][8] bf16 (16x16x32 A fragments)
@@ -71,6 +70,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define OFF_W2 (OFF_B1 + 256 * 4)                  // float [256]
 #define OFF_B2 (OFF_W2 + 256 * 4)                  // float [4]
 #define BLOB_BYTES (OFF_B2 + 16)
+#define LDS_BYTES (OFF_BIAS + S_BYTES)
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
@@ -81,11 +81,11 @@ __device__ __forceinline__ const bf16x8* frag_ptr(const uint8_t* blob, int off, 
     return reinterpret_cast<const bf16x8*>(blob + off) + lane;
 }
 
-// the tower weights go from the blob to LDS once per launch; every thread of the workgroup takes part
-__device__ __forceinline__ void load_tower_weights(const uint8_t* blob, uint8_t* wlds, int tid) {
-    const uint4* src = reinterpret_cast<const uint4*>(blob + OFF_WF);
+// all weight fragments go from the blob to LDS once per launch (77 KB); every thread of the workgroup takes part
+__device__ __forceinline__ void load_weights(const uint8_t* blob, uint8_t* wlds, int tid) {
+    const uint4* src = reinterpret_cast<const uint4*>(blob);
     uint4* dst = reinterpret_cast<uint4*>(wlds);
-    for (int i = tid; i < W_BYTES / 16; i += NTHREADS) dst[i] = src[i];
+    for (int i = tid; i < OFF_BIAS / 16; i += NTHREADS) dst[i] = src[i];
 }
 
 // bf16(ReLU(a)), bf16(ReLU(b)) packed in one dword: convert first, then clamp the two bit patterns
@@ -142,7 +142,7 @@ struct WPair { bf16x8 a0, a1; };                             // the two channel 
 // CONV 0, 1: the block's convs; CONV 2 with KY = KX = 0: the identity
 template <int CONV, int KY, int KX>
 __device__ __forceinline__ WPair wload(const uint8_t* wlds, int lane) {
-    const bf16x8* wf = reinterpret_cast<const bf16x8*>(wlds) + ((CONV * 9 + KY * 3 + KX) * 2) * 64 + lane;
+    const bf16x8* wf = reinterpret_cast<const bf16x8*>(wlds + OFF_WF) + ((CONV * 9 + KY * 3 + KX) * 2) * 64 + lane;
     WPair w;
     w.a0 = wf[0]; w.a1 = wf[64];
     return w;
@@ -232,11 +232,11 @@ __device__ __forceinline__ void between_convs(const uint8_t* wlds, f32x4 (&acc)[
 
 // stem conv 2 -> C straight from the bitboards: the B fragment of row y holds k = tap*2 + plane (18 of 32
 // used) as bf16 1.0 / 0.0, built per lane from the 3x3 window around its cell; leaves the raw accumulators
-__device__ __forceinline__ void stem(const uint8_t* blob, const uint64_t* pos /* this lane's board, or null */,
+__device__ __forceinline__ void stem(const uint8_t* wlds, const uint64_t* pos /* this lane's board, or null */,
                                      f32x4 (&acc)[ROWS][2], const Bias2& b0, int lane) {
     const int p = lane & 15, q = lane >> 4;
     const int x = (p & 7) == 7 ? 0 : (p & 7);                    // pad lanes compute a cell's window, then drop it
-    const bf16x8 a0 = frag_ptr(blob, OFF_SF, lane)[0], a1 = frag_ptr(blob, OFF_SF, lane)[64];
+    const bf16x8 a0 = frag_ptr(wlds, OFF_SF, lane)[0], a1 = frag_ptr(wlds, OFF_SF, lane)[64];
     // After a shift by 8, cell (xx, yy) with xx in -1..7, yy in -1..6 is bit (xx+1)*7 + yy + 1; out-of-board
     // neighbours fall on guard bits, which are zero.  The three window columns of this lane's cell are taken out
     // once per task (nine bits each: rows -1..7), so the per-row work is 32-bit.
@@ -309,7 +309,7 @@ __device__ __forceinline__ void net_rounds(const uint8_t* blob, int num_blocks, 
     // and leaves four boards of head planes in its scratch.  The fully connected heads then run once
     // for the whole workgroup: 8 waves x 4 boards are exactly the 32 columns of an MFMA, wave w owns
     // rows 32w..32w+31 of the value FC and waves 0, 1 the two row tiles of the policy FC, so each
-    // head weight is fetched from L2 once per workgroup and round instead of once per wave and pass.
+    // head weight is read (from LDS) once per workgroup and round instead of once per wave and pass.
     uint8_t* pw = scr + S_PW + wave * PW_BYTES;
     __bf16* hp = reinterpret_cast<__bf16*>(pw + PW_HP);
     __bf16* hv = reinterpret_cast<__bf16*>(pw + PW_HV);
@@ -337,15 +337,13 @@ __device__ __forceinline__ void net_rounds(const uint8_t* blob, int num_blocks, 
             NCOUNT(5);
 #endif
             if (half) { hg2 = g_first; hg3 = g_second; } else { hg0 = g_first; hg1 = g_second; }
-            const uint8_t* sblob = blob;
-            asm volatile("" : "+s"(sblob));
             bf16x8 X[ROWS], Y[ROWS];
             f32x4 acc[ROWS][2];
             const Bias2 b1 = lane_bias(sbias + 32, lane), b2 = lane_bias(sbias + 64, lane);
             {
                 const Bias2 b0 = lane_bias(sbias, lane);
                 const int g_mine = (lane & 8) ? g_second : g_first;
-                stem(sblob, g_mine >= 0 ? position(g_mine) : nullptr, acc, b0, lane);
+                stem(wlds, g_mine >= 0 ? position(g_mine) : nullptr, acc, b0, lane);
             }
             WPair w = wload<0, 1, 1>(wlds, lane);
             if (num_blocks > 0) between_convs<0, true>(wlds, acc, X, b1, w, lane);
@@ -362,9 +360,7 @@ __device__ __forceinline__ void net_rounds(const uint8_t* blob, int num_blocks, 
             NTICK(1);
             // 1x1 head convs as one MFMA per row: rows 0,1 of D = policy planes, row 2 = value plane, which
             // land in the lanes q = 0 (registers 0..2) of each position
-            const uint8_t* hblob = blob;
-            asm volatile("" : "+s"(hblob));
-            const bf16x8 ah = frag_ptr(hblob, OFF_HF, lane)[0];
+            const bf16x8 ah = frag_ptr(wlds, OFF_HF, lane)[0];
             const int p = lane & 15, x = p & 7, bl = (p >> 3) + 2 * half;
 #pragma unroll
             for (int y = 0; y < ROWS; ++y) {
@@ -387,8 +383,6 @@ __device__ __forceinline__ void net_rounds(const uint8_t* blob, int num_blocks, 
         if (worked) NTICK(3); else NTICK(7);
 #endif
 
-        const uint8_t* fblob = blob;
-        asm volatile("" : "+s"(fblob));
         // Thread indices are re-derived from an opaque copy: every address of this phase is then
         // computed here, per round, instead of being kept (and spilled) across the tower.
         int ht = tid;
@@ -406,7 +400,7 @@ __device__ __forceinline__ void net_rounds(const uint8_t* blob, int num_blocks, 
             for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
 #pragma unroll
             for (int s = 0; s < 3; ++s) {
-                const bf16x8 a = frag_ptr(fblob, OFF_F1 + (hw * 3 + s) * 1024, hl)[0];
+                const bf16x8 a = frag_ptr(wlds, OFF_F1 + (hw * 3 + s) * 1024, hl)[0];
                 acc = MFMA(a, *reinterpret_cast<const bf16x8*>(chv + 16 * s + 8 * hh), acc);
             }
 #pragma unroll
@@ -425,7 +419,7 @@ __device__ __forceinline__ void net_rounds(const uint8_t* blob, int num_blocks, 
         if (hw < 2) {
 #pragma unroll
             for (int s = 0; s < 6; ++s) {
-                const bf16x8 a = frag_ptr(fblob, OFF_PF + (hw * 6 + s) * 1024, hl)[0];
+                const bf16x8 a = frag_ptr(wlds, OFF_PF + (hw * 6 + s) * 1024, hl)[0];
                 pacc = MFMA(a, *reinterpret_cast<const bf16x8*>(chp + 16 * s + 8 * hh), pacc);
             }
         }
@@ -463,7 +457,7 @@ __device__ __forceinline__ void net_rounds(const uint8_t* blob, int num_blocks, 
             float sv = 0.0f;
 #pragma unroll
             for (int w = 0; w < 8; ++w) sv += vpart[w * 32 + b];
-            if (gidx >= 0) v_out[gidx] = tanhf(sv + reinterpret_cast<const float*>(fblob + OFF_B2)[0]);
+            if (gidx >= 0) v_out[gidx] = tanhf(sv + sbias[99]);
         }
         NTICK(4);
         if (round + 1 < nrounds) {
