@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # AZHIP_LIBRARY: another build of the same library (tuning builds with in-kernel timers); default: the in-tree one
 LIB_PATH = os.environ.get('AZHIP_LIBRARY') or os.path.join(HERE, 'libazhip.so')
 
-GAME_TTT, GAME_C4 = 0, 1
+GAME_TTT, GAME_C4, GAME_GENERIC = 0, 1, 2
 MAX_ACTIONS, MAX_MOVES = 9, 42
 NO_NODE = 0xFFFFFFFF
 LEAF_NONE, LEAF_EVAL, LEAF_TERMINAL, LEAF_ROOT, LEAF_CACHED = 0, 1, 2, 3, 4
@@ -66,6 +66,9 @@ SIGNATURES = {
     'az_set_position': (C.c_int, [_P, C.c_int32, C.c_uint64, C.c_uint64, C.c_int32, _P, C.c_int32, C.c_uint32]),
     'az_get_tree': (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]),
     'az_node_words': (C.c_int, [_P]),
+    'az_generic_root': (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P]),
+    'az_generic_select': (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), _P, _P]),
+    'az_generic_expand_backup': (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_float, _P]),
     'az_positions_from_history': (C.c_int, [C.c_int32, _P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     'az_game_query': (C.c_int, [C.c_int32, _P, _P, C.c_int32, _P, _P, _P, _P]),
     'az_game_step': (C.c_int, [C.c_int32, _P, _P, _P, C.c_int32, _P, _P]),

@@ -938,6 +938,114 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_run_uniform_p(Dev E, int num_
 }
 
 // ---------------------------------------------------------------------------
+// User-defined games (AZ_GAME_GENERIC): the device keeps the tree and does select / expand / backup with the
+// same numerics; the rules stay with the caller's Game object on the host.  A node has 15 edge records + the
+// count record = 256 B.  The walk needs no rules: the reference never expands a terminal node
+// (mcts.py:131-134), so descending until an edge has no child node ends exactly where mcts.py:123-127 ends;
+// the host replays the returned action indices on a clone of its game and decides terminal / evaluate.
+// One wavefront per call, one game per call: this serves the single-game run_mcts mirror, not throughput.
+// ---------------------------------------------------------------------------
+#define GEN_A 15
+#define GEN_AS 16
+struct GenPrior { float p[GEN_A]; };
+struct GenNoise { double eta[GEN_A]; };
+
+// mcts.py:114-117: expand the root when it has no node yet (n_edges > 0), then blend the noise into its priors
+__global__ void __launch_bounds__(64) k_generic_root(Dev E, int g, int n_edges, GenPrior pr, GenNoise no, int use_noise) {
+    const int lane = lane_id();
+    Slot* s = E.slots + g;
+    uint4* pool = E.pool + (size_t)g * E.cap * GEN_AS;
+    uint32_t root = s->root, alloc = s->alloc, err = s->err;
+    if (root == AZ_NO_NODE && n_edges > 0) {
+        if (alloc < (uint32_t)E.cap) {
+            root = alloc++;
+            if (lane < GEN_AS) {
+                uint4 rec = make_uint4(0u, 0u, lane < n_edges ? __float_as_uint(pr.p[lane < GEN_A ? lane : 0]) : 0u, AZ_NO_NODE);
+                if (lane == GEN_AS - 1) rec = make_uint4((uint32_t)n_edges, 0u, 0u, 0u);
+                pool[(size_t)root * GEN_AS + lane] = rec;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        } else err |= 1u;
+    }
+    if (root != AZ_NO_NODE && use_noise) {
+        const int ne = (int)pool[(size_t)root * GEN_AS + GEN_AS - 1].x;
+        if (lane < ne) {                                   // mcts.py:88-91, as root_noise
+            uint32_t* pp = reinterpret_cast<uint32_t*>(&pool[(size_t)root * GEN_AS + lane]) + 2;
+            const float a = E.one_minus_eps * __uint_as_float(*pp);
+            *pp = __float_as_uint((float)((double)a + E.eps * no.eta[lane]));
+        }
+    }
+    if (lane == 0) { s->root = root; s->alloc = alloc; s->err = err; s->leaf_kind = AZ_LEAF_NONE; s->move_sims = 0; }
+}
+
+// mcts.py:119-127 without the rules: out[0] = depth, out[1 + d] = action index chosen at level d
+__global__ void __launch_bounds__(64) k_generic_select(Dev E, int g, uint32_t* out) {
+    const int lane = lane_id();
+    Slot* s = E.slots + g;
+    const uint4* pool = E.pool + (size_t)g * E.cap * GEN_AS;
+    uint32_t node = s->root;
+    int depth = 0;
+    while (node != AZ_NO_NODE && depth < PATH_LEN) {
+        uint4 e = make_uint4(0u, 0u, 0u, AZ_NO_NODE);
+        if (lane < GEN_AS) e = pool[(size_t)node * GEN_AS + lane];
+        const int n_edges = (int)rdlane(e.x, GEN_AS - 1);
+        const uint32_t Ns = rdlane(e.y, GEN_AS - 1);
+        double cs, sq;
+        lut_lookup(E, Ns, cs, sq);
+        const bool act = lane < n_edges;
+        double score = -INFINITY;
+        if (act) score = puct_score(e.x, __uint_as_float(e.y), __uint_as_float(e.z), cs, sq);
+        const double mx = row16_max(score);
+        const unsigned long long hit = __ballot(act && score == mx) & 0xFFFFull;
+        const int slot = __ffsll((long long)hit) - 1;                   // np.argmax: first maximum
+        if (lane == 0) { s->path[depth] = (node << 4) | (uint32_t)slot; out[1 + depth] = (uint32_t)slot; }
+        depth += 1;
+        node = rdlane(e.w, slot);
+    }
+    if (lane == 0) { s->leaf_depth = depth; s->leaf_kind = AZ_LEAF_EVAL; out[0] = (uint32_t)depth; s->st_steps += (uint64_t)depth; }
+}
+
+// mcts.py:131-158: n_edges > 0: the leaf gets a node with the host's priors (mcts.py:138); v_edge is the value the
+// leaf's edge receives (terminal value, or the network's value already negated, mcts.py:134,144)
+__global__ void __launch_bounds__(64) k_generic_expand_backup(Dev E, int g, int n_edges, GenPrior pr, float v_edge) {
+    const int lane = lane_id();
+    Slot* s = E.slots + g;
+    uint4* pool = E.pool + (size_t)g * E.cap * GEN_AS;
+    const int depth = s->leaf_depth;
+    uint32_t alloc = s->alloc, err = s->err;
+    if (s->leaf_kind != AZ_LEAF_EVAL || depth <= 0) return;
+    if (n_edges > 0) {
+        if (alloc < (uint32_t)E.cap) {
+            const uint32_t idx = alloc++;
+            if (lane < GEN_AS) {
+                uint4 rec = make_uint4(0u, 0u, lane < n_edges ? __float_as_uint(pr.p[lane < GEN_A ? lane : 0]) : 0u, AZ_NO_NODE);
+                if (lane == GEN_AS - 1) rec = make_uint4((uint32_t)n_edges, 0u, 0u, 0u);
+                pool[(size_t)idx * GEN_AS + lane] = rec;
+            }
+            const uint32_t last = s->path[depth - 1];
+            if (lane == 0) reinterpret_cast<uint32_t*>(&pool[(size_t)(last >> 4) * GEN_AS + (last & 15u)])[3] = idx;
+        } else err |= 1u;
+    }
+    for (int d = lane; d < depth; d += 64) {                            // levels are distinct nodes
+        const uint32_t ent = s->path[d];
+        const uint32_t nd = ent >> 4, sl = ent & 15u;
+        uint2* ep = reinterpret_cast<uint2*>(&pool[(size_t)nd * GEN_AS + sl]);
+        uint32_t* ns = reinterpret_cast<uint32_t*>(&pool[(size_t)nd * GEN_AS + GEN_AS - 1]) + 1;
+        uint2 nw = *ep;
+        const float v = ((depth - 1 - d) & 1) ? -v_edge : v_edge;
+        nw.x += 1u;
+        nw.y = __float_as_uint(__uint_as_float(nw.y) + v);
+        *ep = nw;
+        *ns += 1u;
+    }
+    if (lane == 0) {
+        s->alloc = alloc; s->err = err; s->leaf_kind = AZ_LEAF_NONE;
+        s->st_sims += 1; s->move_sims += 1;
+        if (n_edges > 0) s->st_evals += 1;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // stateless bulk kernels (one thread per position)
 // ---------------------------------------------------------------------------
 template <class GM>
@@ -1162,11 +1270,11 @@ static int engine_alloc(az_engine* e) {
         (err = hipMalloc(&d.slots, (size_t)d.G * sizeof(Slot))) != hipSuccess ||
         (err = hipMalloc(&d.rec_visits, (size_t)d.G * AZ_MAX_MOVES * AZ_MAX_ACTIONS * 4)) != hipSuccess ||
         (err = hipMalloc(&d.ring, (size_t)d.ring_cap * sizeof(az_game_record))) != hipSuccess ||
-        (err = hipMalloc(&d.ring_count, 256)) != hipSuccess)
+        (err = hipMalloc(&d.ring_count, 512)) != hipSuccess)
         return az_fail("hipMalloc (node pools)", err);
     HIPCHK(hipMemset(d.slots, 0, (size_t)d.G * sizeof(Slot)));
     HIPCHK(hipMemset(d.rec_visits, 0, (size_t)d.G * AZ_MAX_MOVES * AZ_MAX_ACTIONS * 4));
-    HIPCHK(hipMemset(d.ring_count, 0, 256));
+    HIPCHK(hipMemset(d.ring_count, 0, 512));
     int rc = az_reset_games(e, nullptr);
     if (rc) return rc;
     HIPCHK(hipDeviceSynchronize());
@@ -1176,9 +1284,11 @@ static int engine_alloc(az_engine* e) {
 int az_engine_create(const az_engine_config* cfg, az_engine** out) {
     if (!cfg || !out) return az_fail("null argument");
     *out = nullptr;
-    if (cfg->game != AZ_GAME_C4 && cfg->game != AZ_GAME_TTT) return az_fail("unknown game id");
+    if (cfg->game != AZ_GAME_C4 && cfg->game != AZ_GAME_TTT && cfg->game != AZ_GAME_GENERIC) return az_fail("unknown game id");
     if (cfg->num_games <= 0) return az_fail("num_games must be positive");
     if (cfg->num_simulations < 0) return az_fail("num_simulations must be >= 0");
+    if (cfg->game == AZ_GAME_GENERIC && cfg->node_capacity <= 0)
+        return az_fail("a user-defined game has no move bound: node_capacity must be given");
     const int lmax = cfg->game == AZ_GAME_C4 ? GameC4::LMAX : GameTTT::LMAX;
     long cap = cfg->node_capacity;
     if (cap <= 0) cap = cfg->reuse_search_tree ? (long)cfg->num_simulations * lmax + lmax + 1
@@ -1192,7 +1302,7 @@ int az_engine_create(const az_engine_config* cfg, az_engine** out) {
     if (int rc = scratch_setup(cfg->device)) return rc;
     az_engine* e = new az_engine();
     e->cfg = *cfg;
-    e->A = cfg->game == AZ_GAME_C4 ? GameC4::A : GameTTT::A;
+    e->A = cfg->game == AZ_GAME_C4 ? GameC4::A : cfg->game == AZ_GAME_TTT ? GameTTT::A : GEN_A;
     e->num_cus = cus;
     e->err_flags = 0;
     Dev& d = e->d;
@@ -1228,9 +1338,10 @@ int az_reset_games(az_engine* e, void* stream) {
     if (!e) return az_fail("null engine");
     ENGINE_SCOPE(e);
     hipStream_t st = (hipStream_t)stream;
-    HIPCHK(hipMemsetAsync(e->d.ring_count, 0, 256, st));
+    HIPCHK(hipMemsetAsync(e->d.ring_count, 0, 512, st));
     e->err_flags = 0;
-    DISPATCH_GAME(e->cfg.game, hipLaunchKernelGGL((k_reset<GM>), wave_grid(e->d.G), dim3(BLOCK_THREADS), 0, st, e->d));
+    // the reset touches slots only, whatever the game
+    hipLaunchKernelGGL((k_reset<GameC4>), wave_grid(e->d.G), dim3(BLOCK_THREADS), 0, st, e->d);
     LAUNCH_CHECK();
     return 0;
 }
@@ -1483,6 +1594,58 @@ int az_get_stats(az_engine* e, az_stats* out, void* stream) {
         out->root_evals += s.st_root_evals; out->moves += s.st_moves; out->games += s.st_games;
         out->errors += s.err ? 1 : 0;
     }
+    return 0;
+}
+
+// ---- user-defined games: tree on the device, rules on the host ----------------------------------------------
+static int generic_check(az_engine* e, int32_t g) {
+    if (e->cfg.game != AZ_GAME_GENERIC) return az_fail("this call is for engines created with AZ_GAME_GENERIC");
+    if (g < 0 || g >= e->d.G) return az_fail("bad game slot");
+    return 0;
+}
+
+int az_generic_root(az_engine* e, int32_t g, int32_t n_edges, const float* p_host, const double* eta_host, void* stream) {
+    ENGINE_SCOPE(e);
+    if (int rc = generic_check(e, g)) return rc;
+    if (n_edges < 0 || n_edges > GEN_A) return az_fail("az_generic_root: at most 15 actions");
+    if (n_edges > 0 && !p_host) return az_fail("az_generic_root: priors missing");
+    GenPrior pr; GenNoise no;
+    memset(&pr, 0, sizeof(pr)); memset(&no, 0, sizeof(no));
+    for (int i = 0; i < n_edges; ++i) pr.p[i] = p_host[i];
+    if (eta_host) for (int i = 0; i < GEN_A; ++i) no.eta[i] = eta_host[i];
+    hipLaunchKernelGGL(k_generic_root, dim3(1), dim3(64), 0, (hipStream_t)stream, e->d, (int)g, (int)n_edges, pr, no,
+                       eta_host ? 1 : 0);
+    AZ_LAUNCH_CHECK("k_generic_root");
+    return 0;
+}
+
+int az_generic_select(az_engine* e, int32_t g, int32_t* depth_host, uint8_t* slots_host, void* stream) {
+    ENGINE_SCOPE(e);
+    if (int rc = generic_check(e, g)) return rc;
+    if (!depth_host || !slots_host) return az_fail("null argument");
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t* out = reinterpret_cast<uint32_t*>(e->d.ring_count) + 64;  // the second half of the 512-byte counter block
+    hipLaunchKernelGGL(k_generic_select, dim3(1), dim3(64), 0, st, e->d, (int)g, out);
+    AZ_LAUNCH_CHECK("k_generic_select");
+    uint32_t host[1 + PATH_LEN];
+    HIPCHK(hipMemcpyAsync(host, out, sizeof(host), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *depth_host = (int32_t)host[0];
+    for (uint32_t d = 0; d < host[0] && d < PATH_LEN; ++d) slots_host[d] = (uint8_t)host[1 + d];
+    return 0;
+}
+
+int az_generic_expand_backup(az_engine* e, int32_t g, int32_t n_edges, const float* p_host, float v_edge, void* stream) {
+    ENGINE_SCOPE(e);
+    if (int rc = generic_check(e, g)) return rc;
+    if (n_edges < 0 || n_edges > GEN_A) return az_fail("az_generic_expand_backup: at most 15 actions");
+    if (n_edges > 0 && !p_host) return az_fail("az_generic_expand_backup: priors missing");
+    GenPrior pr;
+    memset(&pr, 0, sizeof(pr));
+    for (int i = 0; i < n_edges; ++i) pr.p[i] = p_host[i];
+    hipLaunchKernelGGL(k_generic_expand_backup, dim3(1), dim3(64), 0, (hipStream_t)stream, e->d, (int)g, (int)n_edges, pr,
+                       v_edge);
+    AZ_LAUNCH_CHECK("k_generic_expand_backup");
     return 0;
 }
 

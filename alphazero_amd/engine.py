@@ -12,7 +12,8 @@ from . import _lib
 from ._lib import (AzError, EngineConfig, GameRecord, Stats, LEAF_EVAL, LEAF_NONE, LEAF_ROOT,
                    LEAF_TERMINAL, NO_NODE, check, ptr)
 
-GAME_SHAPES = {_lib.GAME_TTT: (9, 3, 3, 9), _lib.GAME_C4: (7, 6, 7, 42)}   # A, H, W, max moves
+GAME_SHAPES = {_lib.GAME_TTT: (9, 3, 3, 9), _lib.GAME_C4: (7, 6, 7, 42),      # A, H, W, max moves
+               _lib.GAME_GENERIC: (15, 0, 0, 0)}    # user-defined games: up to 15 actions, rules on the host
 
 
 def make_puct_lut(n, c_base=19652, c_init=1.25):
@@ -200,6 +201,32 @@ class SelfPlayEngine:
         st = Stats()
         check(self.lib.az_get_stats(self.h, C.byref(st), self._stream()))
         return {k: int(getattr(st, k)) for k, _ in Stats._fields_}
+
+    # ---- user-defined games: tree on the device, rules with the caller ----------------
+    def generic_root(self, g, p=None, eta=None):
+        """Expand slot g's root with priors p (when it has no node yet) and blend the noise eta (float64)."""
+        p = None if p is None else np.ascontiguousarray(p, np.float32)
+        if eta is not None:
+            full = np.zeros(15, np.float64)
+            full[:len(eta)] = eta
+            eta = full
+        check(self.lib.az_generic_root(self.h, int(g), 0 if p is None else len(p),
+                                       None if p is None else C.c_void_p(p.ctypes.data),
+                                       None if eta is None else C.c_void_p(eta.ctypes.data), self._stream()))
+
+    def generic_select(self, g):
+        """Action indices from the root to the leaf of slot g's next simulation (synchronises)."""
+        depth = C.c_int32()
+        slots = (C.c_uint8 * 48)()
+        check(self.lib.az_generic_select(self.h, int(g), C.byref(depth), slots, self._stream()))
+        return [int(slots[i]) for i in range(depth.value)]
+
+    def generic_expand_backup(self, g, p, v_edge):
+        """p: priors of the leaf's legal moves (None / empty for a terminal leaf); v_edge: value for the leaf's edge."""
+        p = None if p is None or len(p) == 0 else np.ascontiguousarray(p, np.float32)
+        check(self.lib.az_generic_expand_backup(self.h, int(g), 0 if p is None else len(p),
+                                                None if p is None else C.c_void_p(p.ctypes.data),
+                                                C.c_float(float(np.asarray(v_edge, np.float32).reshape(-1)[0])), self._stream()))
 
     # ---- tree transfer (single-game mirror) -------------------------------------------
     @property

@@ -231,14 +231,47 @@ def _single_engine(game_id, alpha, epsilon, need_nodes):
     return eng
 
 
+def _run_mcts_generic(game, root, model, num_simulations, alpha, epsilon):
+    """run_mcts for a Game subclass the device has no rules for (alphazero/test/test_mcts.py:107-124 is
+    one): the tree, PUCT select, expansion and backup run on the engine (az_generic_*), every rule query
+    (valid_actions, take_action, terminal, terminal_value, render) goes to the caller's Game object,
+    exactly where alphazero/mcts.py:119-145 makes them."""
+    A = 15
+    if game.NUM_ACTIONS > A:
+        raise TypeError(f'run_mcts: user-defined games may have up to {A} actions, got {game.NUM_ACTIONS}')
+    img, objs = _flatten(root, A)
+    eng = _single_engine(_lib.GAME_GENERIC, float(alpha), float(epsilon), img.shape[0] + num_simulations + 2)
+    eng.set_position(0, 0, 0, len(game), img if len(objs) else None, 0 if len(objs) else NO_NODE)
+    # mcts.py:114-117
+    p_root = None
+    if not root.expanded:
+        p_root, _ = evaluate(game, model)
+        n_edges = len(p_root)
+    else:
+        n_edges = len(root.children)
+    eng.generic_root(0, p_root, np.random.dirichlet([alpha] * n_edges))
+    for _ in range(num_simulations):
+        simulation = game.clone()
+        for ai in eng.generic_select(0):                       # mcts.py:123-127
+            simulation.take_action(simulation.valid_actions[ai])
+        if simulation.terminal:                                # mcts.py:131-134
+            eng.generic_expand_backup(0, None, simulation.terminal_value(simulation.prev_player))
+        else:                                                  # mcts.py:135-144
+            p, v = evaluate(simulation, model)
+            assert np.all(p >= 0), f'Node must be expanded with proper, non-negative distribution. Got: {p}'
+            assert abs(float(np.sum(p)) - 1) < 1e-6, f'Node must be expanded with normalized distribution. Got: {p}'
+            eng.generic_expand_backup(0, p, -np.float32(v))
+    st_img, root_idx = eng.get_tree(0)
+    _unflatten(st_img, objs, root, root_idx, A)
+
+
 def run_mcts(game, root, model, num_simulations, alpha=0.3, epsilon=0.25):
     """alphazero/mcts.py:110-158 on the GPU; mutates the tree under `root` in place."""
-    game_id = getattr(game, 'AZ_GAME_ID', None)
-    if game_id is None:
-        raise TypeError('run_mcts runs on the HIP engine and supports the built-in games '
-                        '(ConnectFour, TicTacToe); got ' + type(game).__name__)
     if not torch.cuda.is_available():
         raise _lib.AzError('run_mcts needs a GPU: there is no CPU search path in this package')
+    game_id = getattr(game, 'AZ_GAME_ID', None)
+    if game_id is None:
+        return _run_mcts_generic(game, root, model, num_simulations, alpha, epsilon)
     A = game.NUM_ACTIONS
     img, objs = _flatten(root, A)
     eng = _single_engine(game_id, float(alpha), float(epsilon), img.shape[0] + num_simulations + 2)

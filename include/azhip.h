@@ -31,6 +31,8 @@ extern "C" {
 
 #define AZ_GAME_TTT 0   /* alphazero/games/tictactoe.py:9-62   : 9 actions, 3x3 */
 #define AZ_GAME_C4  1   /* alphazero/games/connectfour.py:75-120: 7 actions, 6x7 */
+#define AZ_GAME_GENERIC 2 /* any alphazero/game.py:5-65 subclass with <= 15 actions: the tree lives on the
+                             device, the rules stay with the caller (az_generic_* below)                 */
 
 #define AZ_MAX_ACTIONS 9
 #define AZ_MAX_MOVES   42
@@ -192,6 +194,23 @@ int  az_set_position(az_engine* e, int32_t g, uint64_t bb_next, uint64_t bb_prev
 int  az_get_tree(az_engine* e, int32_t g, uint32_t* nodes_host, int32_t max_nodes,
                  int32_t* num_nodes, uint32_t* root_node);
 int  az_node_words(const az_engine* e);   /* uint32 words per node = 4*(A+1) */
+
+/* ---- user-defined games (engine created with AZ_GAME_GENERIC, node_capacity given) ---------------------
+ * The search tree, PUCT select, expansion and backup run on the device with the numerics of the built-in
+ * games; the Game object (alphazero/game.py:5-65: valid_actions, take_action, terminal, terminal_value,
+ * render) is only ever touched by the caller.  Per simulation (alphazero/mcts.py:119-158):
+ *   az_generic_select         -> depth and the action INDICES chosen from the root (mcts.py:123-127); the caller
+ *                                replays them on a clone of its game (a terminal state is never expanded, so
+ *                                the walk ends on it or on an un-expanded edge, as the reference's does)
+ *   az_generic_expand_backup  <- n_edges = number of legal moves at the leaf and their priors (0 for a terminal
+ *                                leaf: nothing is expanded), v_edge = the value for the leaf's edge: the
+ *                                terminal value (mcts.py:134) or the evaluator's value negated (mcts.py:144)
+ * az_generic_root expands the root when it has no node yet (n_edges, priors) and, when eta is given, blends
+ * the Dirichlet noise (mcts.py:114-117).  Host pointers; az_generic_select is synchronous.  Trees go in and
+ * out with az_set_position / az_get_tree (A = 15: 64 words per node).  One game per call.               */
+int  az_generic_root(az_engine* e, int32_t g, int32_t n_edges, const float* p_host, const double* eta_host, void* stream);
+int  az_generic_select(az_engine* e, int32_t g, int32_t* depth_host, uint8_t* slots_host, void* stream);
+int  az_generic_expand_backup(az_engine* e, int32_t g, int32_t n_edges, const float* p_host, float v_edge, void* stream);
 
 /* ---- stateless bulk game kernels (K1-K4), DEVICE buffers -----------------
  * hist uint8[n][stride], len int32[n]  ->  bitboards + rule queries
