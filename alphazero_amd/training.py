@@ -1,6 +1,8 @@
 """TrainingWorker with the reference's constructor and process_batch() contract
 (alphazero/training.py:15-125): SGD + momentum + weight decay, MultiStepLR, masked
-cross-entropy + MSE, weights published after every step.  Host-side torch code; the summary
+cross-entropy + MSE, weights published after every step.  On the GPU the loss with its gradients and the
+optimiser update are hand-written kernels (loss.AlphaZeroLoss, optim.FlatSGD; csrc/az_train.hip); the network's
+forward and backward in between are PyTorch's.  The summary
 writer and model server are duck-typed (`add_scalar`, `update(model, version)`).  `dataset` is a
 ReplayBufferDataset (the reference's per-state sample dicts) or a DeviceReplayWindow (batches taken
 straight from tensors on the GPU)."""
@@ -26,8 +28,14 @@ class TrainingWorker:
         self._model = config.Model().to(device)
         self._loss = config.Loss()
         t = config.training
-        self._optimizer = SGD(self._model.parameters(), lr=t['lr'], momentum=t['momentum'],
-                              weight_decay=t['weight_decay'])
+        if torch.device(device).type == 'cuda':
+            # one launch per step over a flat parameter buffer (csrc/az_train.hip)
+            from .optim import FlatSGD
+            self._optimizer = FlatSGD(self._model.parameters(), lr=t['lr'], momentum=t['momentum'],
+                                      weight_decay=t['weight_decay'])
+        else:
+            self._optimizer = SGD(self._model.parameters(), lr=t['lr'], momentum=t['momentum'],
+                                  weight_decay=t['weight_decay'])
         self._lr_schedule = MultiStepLR(self._optimizer, t['lr_schedule'], gamma=t['lr_schedule_gamma'])
         self._sampler = ReplayBufferSampler(dataset, batch_size=self._batch_size, bufferlen=64 * 1024)
         self._iter = 0

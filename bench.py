@@ -593,6 +593,65 @@ def main():
             out['agreement'] = measure_agreement(dev, fused, f32, S)
             # (c) BASELINE config 4
             out['config4_leaf_eval'] = config4_leaf_eval(dev)
+            # (d) BASELINE config 5 on one GPU: the training step on the device-resident replay window, alone
+            # and inside the self-play loop (one SGD step and one weight hand-over per lock-step move, as the
+            # reference's synchronous mode alternates them, alphazero/train.py:86-96)
+            from alphazero_amd.config import AlphaZeroConfig
+            from alphazero_amd.games import ConnectFour
+            from alphazero_amd.replay_buffer import DeviceReplayWindow
+            from alphazero_amd.training import TrainingWorker
+            tcfg = AlphaZeroConfig(conf={
+                'game': {'module': 'alphazero.games.connectfour', 'name': 'ConnectFour'},
+                'model': {'module': 'alphazero.games.connectfour', 'name': 'AlphaZeroC4',
+                          'kwargs': {'num_blocks': blocks, 'channels_per_block': ch}},
+                'loss': {'module': 'alphazero.loss', 'name': 'AlphaZeroLoss'},
+                'training': {'num_steps': 10000, 'batch_size': 128, 'lr': 0.2, 'momentum': 0.9, 'weight_decay': 1e-4,
+                             'lr_schedule_gamma': 0.1, 'lr_schedule': [1000, 2000, 4000]}})   # config/connectfour.yaml:13-20
+
+            class _Publish:
+                def update(self, model, version):
+                    self.version = version
+            window = DeviceReplayWindow(ConnectFour, 64 * 1024, dev)
+            stepwise_now[0] = False
+
+            def play_and_collect():
+                one_step(False)
+                recs, head = eng.take_finished_device()
+                n_rec, flags = head.tolist()
+                assert flags == 0
+                window.add_records_device(recs[:n_rec])
+            while len(window) < 8 * 128:
+                play_and_collect()
+            torch.manual_seed(0)
+            tw = TrainingWorker(tcfg, _Publish(), window, None, dev)
+            for _ in range(3):
+                tw.process_batch()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(20):
+                tw.process_batch()
+            torch.cuda.synchronize()
+            train_ms = 1e3 * (time.perf_counter() - t1) / 20
+            play_and_collect()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            loop_steps = 4
+            for _ in range(loop_steps):
+                play_and_collect()
+                v_new = tw.process_batch()
+                fused.load_module(tw.model)                  # the new weights reach the self-play kernels
+                eng.set_model_version(v_new)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / loop_steps
+            out['config5_train_loop'] = {
+                'training_step_ms': train_ms, 'batch_size': 128, 'samples_per_s': 128 / (train_ms * 1e-3),
+                'step': 'sample from the device window + forward + az_loss_fwd_bwd + backward + az_sgd_momentum + publish',
+                'selfplay_with_training': {'value': G / dt, 'unit': 'positions/s', 'ms_per_step': 1e3 * dt,
+                                           'steps': loop_steps,
+                                           'per_step': 'one lock-step move (records stay on the device) + one SGD step + '
+                                                       're-pack of the weights for the self-play kernels'},
+                'window_states': len(window), 'note': 'one GPU; with N ranks the records are gathered on the trainer rank '
+                                                      'and the packed weights broadcast (see config.exchange)'}
         if not args.no_cpu_baseline and world == 1:      # the host-CPU baseline is timed at N = 1 only
             logical, physical = physical_cores()
             workers = cpu_share()

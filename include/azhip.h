@@ -299,6 +299,21 @@ int  az_tttnet_f32_blob_floats(int32_t channels);
 int  az_tttnet_f32_forward(const float* blob, int32_t channels, int32_t num_blocks, const uint64_t* leaf_bb,
                            const int32_t* leaf_info, int32_t n, float* p, float* v, void* stream);
 
+/* ---- training step, the hand-written parts (alphazero/training.py:42-75) ---------------------------------
+ * az_loss_fwd_bwd: AlphaZeroLoss (alphazero/loss.py:29-63) and its gradients in one launch.  DEVICE buffers:
+ * logits float[B][A] (the network's raw policy output), v_hat float[B], target float[B][A] (search
+ * distribution), z float[B], valid uint8[B][A]  ->  out3 float[3] = {policy loss = batch mean of the masked
+ * cross-entropy, value loss = batch mean of (z - v_hat)^2, max |sum(target) - 1| (the reference asserts it is
+ * below 1e-6, loss.py:58-59)}, dlogits float[B][A] and dv float[B] = gradients of (policy loss) and (value
+ * loss) with respect to logits and v_hat.  A = 7 or 9.
+ * az_sgd_momentum: torch.optim.SGD's update as the reference configures it (training.py:27-29: momentum,
+ * weight decay, no dampening) over one flat fp32 buffer of n elements: d = grad + wd*p; buf = first_step ? d :
+ * momentum*buf + d; p -= lr*buf.                                                                          */
+int  az_loss_fwd_bwd(int32_t num_actions, const float* logits, const float* v_hat, const float* target, const float* z,
+                     const uint8_t* valid, int32_t batch, float* out3, float* dlogits, float* dv, void* stream);
+int  az_sgd_momentum(float* params, const float* grads, float* momentum_buf, int64_t n, float lr, float momentum,
+                     float weight_decay, int32_t first_step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,123 @@
+"""The training step on the GPU (alphazero/training.py:42-75): the hand-written loss and optimiser kernels
+against their torch statements, and four whole steps against the scalars the reference's own TrainingWorker
+logged for the same seeds, data and configuration."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_json, unhex
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('A,B', [(7, 128), (9, 37), (7, 1), (9, 1000)])
+def test_loss_kernel_matches_the_torch_statement(A, B):
+    from alphazero_amd.loss import AlphaZeroLoss, masked_cross_entropy
+    g = torch.Generator().manual_seed(A * 1000 + B)
+    valid = torch.rand(B, A, generator=g) < 0.7
+    valid[:, 0] |= ~valid.any(1)                                   # at least one legal move
+    t = torch.rand(B, A, generator=g) * valid
+    t[torch.rand(B, A, generator=g) < 0.2] = 0                     # zero targets inside the mask
+    t[:, 0] += (t.sum(1) == 0) * valid[:, 0]
+    t = t * valid
+    fix = t.sum(1) == 0
+    t[fix] = valid[fix].float()
+    t = t / t.sum(1, keepdim=True)
+    z = torch.sign(torch.randn(B, 1, generator=g))
+    logits = (3 * torch.randn(B, A, generator=g)).requires_grad_()
+    v = torch.tanh(torch.randn(B, 1, generator=g)).requires_grad_()
+    # torch statement on the CPU (the one pinned to the reference's recorded scalars)
+    pl = masked_cross_entropy(logits, t, valid).mean()
+    vl = ((z - v) ** 2).mean()
+    (1.7 * pl + 0.3 * vl).backward()
+    lg, vg = logits.detach().cuda().requires_grad_(), v.detach().cuda().requires_grad_()
+    pl2, vl2 = AlphaZeroLoss()(t.cuda(), z.cuda(), lg, vg, valid.cuda())
+    (1.7 * pl2 + 0.3 * vl2).backward()
+    assert abs(pl2.item() - pl.item()) <= 1e-6 * max(1, abs(pl.item()))
+    assert abs(vl2.item() - vl.item()) <= 1e-6 * max(1, abs(vl.item()))
+    assert torch.allclose(lg.grad.cpu(), logits.grad, rtol=1e-5, atol=1e-7)
+    assert torch.allclose(vg.grad.cpu(), v.grad, rtol=1e-5, atol=1e-7)
+    assert torch.all(lg.grad.cpu()[~valid] == 0)
+
+
+def test_loss_kernel_keeps_the_reference_assertion():
+    from alphazero_amd.loss import AlphaZeroLoss
+    p = torch.full((4, 7), 0.2, device='cuda')                     # sums to 1.4
+    with pytest.raises(AssertionError, match='valid distribution'):
+        AlphaZeroLoss()(p, torch.zeros(4, 1, device='cuda'), torch.zeros(4, 7, device='cuda'),
+                        torch.zeros(4, 1, device='cuda'), torch.ones(4, 7, dtype=torch.bool, device='cuda'))
+
+
+def test_flat_sgd_matches_torch_sgd():
+    from alphazero_amd.models import AlphaZeroC4
+    from alphazero_amd.optim import FlatSGD
+    from torch.optim.lr_scheduler import MultiStepLR
+    torch.manual_seed(4)
+    a = AlphaZeroC4(2, 8).cuda()
+    torch.manual_seed(4)
+    b = AlphaZeroC4(2, 8).cuda()
+    oa = torch.optim.SGD(a.parameters(), lr=0.2, momentum=0.9, weight_decay=1e-4)
+    ob = FlatSGD(b.parameters(), lr=0.2, momentum=0.9, weight_decay=1e-4)
+    sa, sb = MultiStepLR(oa, [2, 4], gamma=0.1), MultiStepLR(ob, [2, 4], gamma=0.1)
+    sd = b.state_dict()
+    assert sd['_tower.0._c1.weight'].data_ptr() == sd['_tower.1._c1.weight'].data_ptr()     # aliases survive the flattening
+    g = torch.Generator().manual_seed(1)
+    for step in range(6):
+        x = (torch.rand(32, 2, 6, 7, generator=g) < 0.3).float().cuda()
+        valid = torch.ones(32, 7, dtype=torch.bool, device='cuda')
+        for m, o, s in ((a, oa, sa), (b, ob, sb)):
+            m.train()
+            o.zero_grad()
+            p_hat, v_hat = m(x, valid)
+            (p_hat.square().mean() + v_hat.square().mean()).backward()
+            o.step()
+            s.step()
+        assert sa.get_last_lr() == sb.get_last_lr()
+        for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+            assert torch.allclose(pa, pb, rtol=2e-5, atol=1e-6), (step, k, (pa - pb).abs().max().item())
+
+
+def test_training_steps_on_the_gpu_match_the_reference_scalars():
+    """host.json 'training': four process_batch() calls of the reference's TrainingWorker on the CPU.  The same
+    seeds, games and configuration here with the model on the GPU, the HIP loss kernel and FlatSGD: every logged
+    scalar within 1e-5 relative, the final weights within 1e-4 (vendor convolutions, different summation order)."""
+    from test_host_cpu import _golden_game
+    from alphazero_amd.config import AlphaZeroConfig
+    from alphazero_amd.optim import FlatSGD
+    from alphazero_amd.replay_buffer import ReplayBufferDataset
+    from alphazero_amd.training import TrainingWorker
+    t = load_json('host.json')['training']
+    cfg = AlphaZeroConfig(conf=t['conf'])
+    ds = ReplayBufferDataset(cfg)
+    for g in t['games']:
+        ds.add_game(_golden_game(cfg, g), 1)
+
+    class Server:
+        versions = []
+
+        def update(self, model, version):
+            self.versions.append(int(version))
+
+    class Writer:
+        rows = []
+
+        def add_scalar(self, tag, value, step):
+            self.rows.append([tag, float(value), int(step)])
+
+    torch.manual_seed(t['model_seed'])
+    np.random.seed(t['sampler_seed'])
+    server, writer = Server(), Writer()
+    tw = TrainingWorker(cfg, server, ds, writer, 'cuda', 0)
+    assert isinstance(tw._optimizer, FlatSGD)
+    assert [tw.process_batch() for _ in range(4)] == t['returns'] and server.versions == t['versions']
+    assert [(r[0], r[2]) for r in writer.rows] == [(r[0], r[2]) for r in t['scalars']]
+    worst = 0.0
+    for got, want in zip(writer.rows, t['scalars']):
+        err = abs(got[1] - want[1]) / max(1.0, abs(want[1]))
+        worst = max(worst, err)
+        assert err <= 1e-5, (got, want)
+    state = tw.model.state_dict()
+    for k, h in t['final'].items():
+        a, b = state[k].detach().cpu().numpy().reshape(-1), unhex(h, '<f4')
+        assert np.allclose(a, b, rtol=1e-4, atol=1e-5), (k, np.abs(a - b).max())
+    print('worst relative scalar error vs the reference:', worst)
