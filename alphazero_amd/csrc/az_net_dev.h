@@ -148,11 +148,12 @@ __device__ __forceinline__ WPair wload(const uint8_t* wlds, int lane) {
     return w;
 }
 
-// the row's fragment as seen one cell to the left (LEFT: lane p reads lane p - 1) or to the right, zero at
-// the ends of the 16-lane row
-template <bool LEFT>
-__device__ __forceinline__ bf16x8 shift_cell(const bf16x8& v) {
-    constexpr int CTRL = LEFT ? 0x111 : 0x101;               // row_shr:1 / row_shl:1
+// A task is two boards (NT = 6 tiles: tile y = row y of both boards) or ONE board folded onto itself (NT = 3
+// tiles: tile t = row t in lanes 0..7 and row t + 3 in lanes 8..15), which costs little more than half: a lone
+// leaf does not pay for an empty partner.  Folded, the row above tile 0 is [nothing | row 2] and the row below
+// tile 2 is [row 3 | nothing]: the neighbouring tile moved by eight lanes.
+template <int CTRL>
+__device__ __forceinline__ bf16x8 dpp_frag(const bf16x8& v) {
     const uint4 u = __builtin_bit_cast(uint4, v);
     uint4 r;
     r.x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u.x, CTRL, 0xF, 0xF, true);
@@ -161,62 +162,83 @@ __device__ __forceinline__ bf16x8 shift_cell(const bf16x8& v) {
     r.w = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u.w, CTRL, 0xF, 0xF, true);
     return __builtin_bit_cast(bf16x8, r);
 }
+// the row's fragment as seen one cell to the left (LEFT: lane p reads lane p - 1, row_shr:1) or to the right
+// (row_shl:1), zero at the ends of the 16-lane row
+template <bool LEFT>
+__device__ __forceinline__ bf16x8 shift_cell(const bf16x8& v) { return dpp_frag<LEFT ? 0x111 : 0x101>(v); }
+// folded tasks: lanes 8..15 <- lanes 0..7 and zeros below (row_shr:8), or lanes 0..7 <- lanes 8..15 (row_shl:8)
+__device__ __forceinline__ bf16x8 fold_up(const bf16x8& v) { return dpp_frag<0x118>(v); }
+__device__ __forceinline__ bf16x8 fold_down(const bf16x8& v) { return dpp_frag<0x108>(v); }
 
 // the MFMAs of one tap: output row y takes input row y + KY - 1 (rows -1 and 6 do not exist)
-template <int KY>
-__device__ __forceinline__ void tap_rows(f32x4 (&acc)[ROWS][2], const bf16x8 (&s)[ROWS], const WPair& w) {
+template <int KY, int NT>
+__device__ __forceinline__ void tap_rows(f32x4 (&acc)[NT][2], const bf16x8 (&s)[NT], const WPair& w) {
+    if (NT == ROWS) {
 #pragma unroll
-    for (int y = 0; y < ROWS; ++y) {
-        const int yy = y + KY - 1;
-        if (yy < 0 || yy >= ROWS) continue;
-        acc[y][0] = MFMA16(w.a0, s[yy], acc[y][0]);
-        acc[y][1] = MFMA16(w.a1, s[yy], acc[y][1]);
+        for (int y = 0; y < NT; ++y) {
+            const int yy = y + KY - 1;
+            if (yy < 0 || yy >= NT) continue;
+            acc[y][0] = MFMA16(w.a0, s[yy], acc[y][0]);
+            acc[y][1] = MFMA16(w.a1, s[yy], acc[y][1]);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int tt = t + KY - 1;
+            const bf16x8 b = tt < 0 ? fold_up(s[NT - 1]) : (tt >= NT ? fold_down(s[0]) : s[tt]);
+            acc[t][0] = MFMA16(w.a0, b, acc[t][0]);
+            acc[t][1] = MFMA16(w.a1, b, acc[t][1]);
+        }
     }
 }
 
 // The eight taps around the centre of conv CONV over `in`, plus (RES) the identity tap over `res`.  On entry
 // w = weights of tap (0,1) of CONV, on exit w = weights of the centre tap of conv NEXT.
-template <int CONV, int NEXT, bool RES>
-__device__ __forceinline__ void conv_rest(const uint8_t* wlds, const bf16x8 (&in)[ROWS], const bf16x8 (&res)[ROWS],
-                                          f32x4 (&acc)[ROWS][2], WPair& w, int lane) {
+template <int CONV, int NEXT, bool RES, int NT>
+__device__ __forceinline__ void conv_rest(const uint8_t* wlds, const bf16x8 (&in)[NT], const bf16x8 (&res)[NT],
+                                          f32x4 (&acc)[NT][2], WPair& w, int lane) {
     WPair n;
-    bf16x8 sl[ROWS], sr[ROWS];
+    bf16x8 sl[NT], sr[NT];
+    constexpr int H = NT / 2 + (NT & 1), T3 = NT / 3;
     // centre column of the window; meanwhile the rows as seen from the right-hand neighbour (window column 0)
-    n = wload<CONV, 2, 1>(wlds, lane); tap_rows<0>(acc, in, w);
+    n = wload<CONV, 2, 1>(wlds, lane); tap_rows<0, NT>(acc, in, w);
 #pragma unroll
-    for (int y = 0; y < 3; ++y) sl[y] = shift_cell<true>(in[y]);
+    for (int y = 0; y < H; ++y) sl[y] = shift_cell<true>(in[y]);
     w = n; FENCE();
-    n = RES ? wload<2, 0, 0>(wlds, lane) : wload<CONV, 1, 0>(wlds, lane); tap_rows<2>(acc, in, w);
+    n = RES ? wload<2, 0, 0>(wlds, lane) : wload<CONV, 1, 0>(wlds, lane); tap_rows<2, NT>(acc, in, w);
 #pragma unroll
-    for (int y = 3; y < ROWS; ++y) sl[y] = shift_cell<true>(in[y]);
+    for (int y = H; y < NT; ++y) sl[y] = shift_cell<true>(in[y]);
     w = n; FENCE();
     if (RES) {
-        n = wload<CONV, 1, 0>(wlds, lane); tap_rows<1>(acc, res, w); w = n; FENCE();
+        n = wload<CONV, 1, 0>(wlds, lane); tap_rows<1, NT>(acc, res, w); w = n; FENCE();
     }
     // window column 0; meanwhile the rows as seen from the left-hand neighbour (window column 2)
-    n = wload<CONV, 0, 0>(wlds, lane); tap_rows<1>(acc, sl, w);
-    sr[0] = shift_cell<false>(in[0]); sr[1] = shift_cell<false>(in[1]);
+    n = wload<CONV, 0, 0>(wlds, lane); tap_rows<1, NT>(acc, sl, w);
+#pragma unroll
+    for (int y = 0; y < T3; ++y) sr[y] = shift_cell<false>(in[y]);
     w = n; FENCE();
-    n = wload<CONV, 2, 0>(wlds, lane); tap_rows<0>(acc, sl, w);
-    sr[2] = shift_cell<false>(in[2]); sr[3] = shift_cell<false>(in[3]);
+    n = wload<CONV, 2, 0>(wlds, lane); tap_rows<0, NT>(acc, sl, w);
+#pragma unroll
+    for (int y = T3; y < 2 * T3; ++y) sr[y] = shift_cell<false>(in[y]);
     w = n; FENCE();
-    n = wload<CONV, 1, 2>(wlds, lane); tap_rows<2>(acc, sl, w);
-    sr[4] = shift_cell<false>(in[4]); sr[5] = shift_cell<false>(in[5]);
+    n = wload<CONV, 1, 2>(wlds, lane); tap_rows<2, NT>(acc, sl, w);
+#pragma unroll
+    for (int y = 2 * T3; y < NT; ++y) sr[y] = shift_cell<false>(in[y]);
     w = n; FENCE();
     // window column 2
-    n = wload<CONV, 0, 2>(wlds, lane); tap_rows<1>(acc, sr, w); w = n; FENCE();
-    n = wload<CONV, 2, 2>(wlds, lane); tap_rows<0>(acc, sr, w); w = n; FENCE();
-    n = wload<NEXT, 1, 1>(wlds, lane); tap_rows<2>(acc, sr, w); w = n; FENCE();
+    n = wload<CONV, 0, 2>(wlds, lane); tap_rows<1, NT>(acc, sr, w); w = n; FENCE();
+    n = wload<CONV, 2, 2>(wlds, lane); tap_rows<0, NT>(acc, sr, w); w = n; FENCE();
+    n = wload<NEXT, 1, 1>(wlds, lane); tap_rows<2, NT>(acc, sr, w); w = n; FENCE();
 }
 
 // Between two convs: acc -> out (ReLU, bf16) and, when CENTRE, the centre tap of the next conv with its bias as
 // the C operand.  On entry w = centre weights of conv NEXT, on exit w = weights of its tap (0,1).
-template <int NEXT, bool CENTRE>
-__device__ __forceinline__ void between_convs(const uint8_t* wlds, f32x4 (&acc)[ROWS][2], bf16x8 (&out)[ROWS],
+template <int NEXT, bool CENTRE, int NT>
+__device__ __forceinline__ void between_convs(const uint8_t* wlds, f32x4 (&acc)[NT][2], bf16x8 (&out)[NT],
                                               const Bias2& bias, WPair& w, int lane) {
     const WPair n = wload<NEXT, 0, 1>(wlds, lane);
 #pragma unroll
-    for (int y = 0; y < ROWS; ++y) {
+    for (int y = 0; y < NT; ++y) {
         const f32x4 c0 = acc[y][0], c1 = acc[y][1];
         out[y] = __builtin_bit_cast(bf16x8, make_uint4(relu_bf16x2(c0[0], c0[1]), relu_bf16x2(c0[2], c0[3]),
                                                        relu_bf16x2(c1[0], c1[1]), relu_bf16x2(c1[2], c1[3])));
@@ -230,39 +252,36 @@ __device__ __forceinline__ void between_convs(const uint8_t* wlds, f32x4 (&acc)[
     FENCE();
 }
 
-// stem conv 2 -> C straight from the bitboards: the B fragment of row y holds k = tap*2 + plane (18 of 32
-// used) as bf16 1.0 / 0.0, built per lane from the 3x3 window around its cell; leaves the raw accumulators
+// stem conv 2 -> C straight from the bitboards.  The B fragment of a tile holds the 3x3x2 window around each
+// cell as bf16 1.0 / 0.0 in the k order that is cheapest to extract: k = 9 * column + 3 * plane + row of the window
+// (18 of 32 used; the stem's weights are packed in the same order, alphazero_amd/net.py).  Leaves the raw
+// accumulators.
+template <int NT>
 __device__ __forceinline__ void stem(const uint8_t* wlds, const uint64_t* pos /* this lane's board, or null */,
-                                     f32x4 (&acc)[ROWS][2], const Bias2& b0, int lane) {
+                                     f32x4 (&acc)[NT][2], const Bias2& b0, int lane) {
     const int p = lane & 15, q = lane >> 4;
     const int x = (p & 7) == 7 ? 0 : (p & 7);                    // pad lanes compute a cell's window, then drop it
+    const int row0 = NT == ROWS ? 0 : 3 * (p >> 3);              // folded: the upper lanes hold rows 3..5
     const bf16x8 a0 = frag_ptr(wlds, OFF_SF, lane)[0], a1 = frag_ptr(wlds, OFF_SF, lane)[64];
     // After a shift by 8, cell (xx, yy) with xx in -1..7, yy in -1..6 is bit (xx+1)*7 + yy + 1; out-of-board
     // neighbours fall on guard bits, which are zero.  The three window columns of this lane's cell are taken out
-    // once per task (nine bits each: rows -1..7), so the per-row work is 32-bit.
-    uint32_t col[2][3] = {{0, 0, 0}, {0, 0, 0}};
+    // once per task, nine bits each (rows -1..7), side by side in one word per plane.
+    uint32_t cols[2] = {0, 0};
     if (pos) {
 #pragma unroll
         for (int plane = 0; plane < 2; ++plane) {
             const uint64_t b = pos[plane] << 8;
 #pragma unroll
-            for (int tx = 0; tx < 3; ++tx) col[plane][tx] = (uint32_t)(b >> ((x + tx) * 7)) & 0x1FFu;
+            for (int tx = 0; tx < 3; ++tx) cols[plane] |= ((uint32_t)(b >> ((x + tx) * 7)) & 0x1FFu) << (9 * tx);
         }
     }
 #pragma unroll
-    for (int y = 0; y < ROWS; ++y) {
-        // three rows of one window column are three consecutive bits; m18 collects the 3x3x2 window as
-        // bit k = 2 * tap + plane, tap = 3 * row + column of the window
-        uint32_t m18 = 0;
-#pragma unroll
-        for (int plane = 0; plane < 2; ++plane)
-#pragma unroll
-            for (int tx = 0; tx < 3; ++tx) {
-                const uint32_t c3 = (col[plane][tx] >> y) & 7u;                            // rows ty = 0, 1, 2
-                m18 |= ((c3 * 0x421u) & 0x1041u) << (2 * tx + plane);                      // to bits 0, 6, 12
-            }
-        // this lane's eight k are bits 8q..8q+7 (nothing beyond bit 17): two per dword
-        const uint32_t k8 = (m18 >> (8 * q)) & 0xFFu;
+    for (int t = 0; t < NT; ++t) {
+        const int y = t + row0;
+        // rows y-1, y, y+1 of the three columns: bits 0..2, 9..11, 18..20; the second plane goes three bits up
+        const uint32_t m = ((cols[0] >> y) & 0x1C0E07u) | (((cols[1] >> y) & 0x1C0E07u) << 3);
+        // this lane's eight k are bits 8q..8q+7: two per dword
+        const uint32_t k8 = (m >> (8 * q)) & 0xFFu;
         uint32_t d[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -270,8 +289,50 @@ __device__ __forceinline__ void stem(const uint8_t* wlds, const uint64_t* pos /*
             d[i] = (t2 & 1u) * 0x3F80u + (t2 >> 1) * 0x3F800000u;
         }
         const bf16x8 f = __builtin_bit_cast(bf16x8, make_uint4(d[0], d[1], d[2], d[3]));
-        acc[y][0] = MFMA16(a0, f, b0.h0);
-        acc[y][1] = MFMA16(a1, f, b0.h1);
+        acc[t][0] = MFMA16(a0, f, b0.h0);
+        acc[t][1] = MFMA16(a1, f, b0.h1);
+    }
+}
+
+// One task from the bitboards to the head planes: stem, tower, 1x1 head convs.  pos = this lane's board (the
+// lane's half of a two-board task, or the one board of a folded task), null when there is none; planes of board
+// slot bl0 (+1 for the second board) of this wave's scratch receive the ReLU'd head-conv outputs.
+template <int NT>
+__device__ __forceinline__ void trunk_task(const uint8_t* wlds, const float* sbias, int num_blocks, const uint64_t* pos,
+                                           __bf16* hp, __bf16* hv, int bl0, int lane) {
+    bf16x8 X[NT], Y[NT];
+    f32x4 acc[NT][2];
+    const Bias2 b1 = lane_bias(sbias + 32, lane), b2 = lane_bias(sbias + 64, lane);
+    {
+        const Bias2 b0 = lane_bias(sbias, lane);
+        stem<NT>(wlds, pos, acc, b0, lane);
+    }
+    WPair w = wload<0, 1, 1>(wlds, lane);
+    if (num_blocks > 0) between_convs<0, true, NT>(wlds, acc, X, b1, w, lane);
+    else between_convs<0, false, NT>(wlds, acc, X, b1, w, lane);
+#pragma unroll 1
+    for (int blk = 0; blk < num_blocks; ++blk) {
+        conv_rest<0, 1, false, NT>(wlds, X, X, acc, w, lane);
+        between_convs<1, true, NT>(wlds, acc, Y, b2, w, lane);
+        conv_rest<1, 0, true, NT>(wlds, Y, X, acc, w, lane);
+        if (blk + 1 < num_blocks) between_convs<0, true, NT>(wlds, acc, X, b1, w, lane);
+        else between_convs<0, false, NT>(wlds, acc, X, b1, w, lane);
+    }
+    // 1x1 head convs as one MFMA per tile: rows 0,1 of D = policy planes, row 2 = value plane, which land in the
+    // lanes q = 0 (registers 0..2) of each position
+    const bf16x8 ah = frag_ptr(wlds, OFF_HF, lane)[0];
+    const int p = lane & 15, x = p & 7;
+    const int bl = NT == ROWS ? bl0 + (p >> 3) : bl0, row0 = NT == ROWS ? 0 : 3 * (p >> 3);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        const f32x4 d = MFMA16(ah, X[t], z4);
+        if (lane < 16 && x != 7) {
+            const int cell = (t + row0) * 7 + x;
+            hp[bl * 96 + cell] = (__bf16)fmaxf(d[0] + sbias[96], 0.0f);
+            hp[bl * 96 + 42 + cell] = (__bf16)fmaxf(d[1] + sbias[97], 0.0f);
+            hv[bl * 48 + cell] = (__bf16)fmaxf(d[2] + sbias[98], 0.0f);
+        }
     }
 }
 
@@ -337,42 +398,13 @@ __device__ __forceinline__ void net_rounds(const uint8_t* blob, int num_blocks, 
             NCOUNT(5);
 #endif
             if (half) { hg2 = g_first; hg3 = g_second; } else { hg0 = g_first; hg1 = g_second; }
-            bf16x8 X[ROWS], Y[ROWS];
-            f32x4 acc[ROWS][2];
-            const Bias2 b1 = lane_bias(sbias + 32, lane), b2 = lane_bias(sbias + 64, lane);
-            {
-                const Bias2 b0 = lane_bias(sbias, lane);
+            if (g_second >= 0) {
                 const int g_mine = (lane & 8) ? g_second : g_first;
-                stem(wlds, g_mine >= 0 ? position(g_mine) : nullptr, acc, b0, lane);
-            }
-            WPair w = wload<0, 1, 1>(wlds, lane);
-            if (num_blocks > 0) between_convs<0, true>(wlds, acc, X, b1, w, lane);
-            else between_convs<0, false>(wlds, acc, X, b1, w, lane);
-            NTICK(0);
-#pragma unroll 1
-            for (int blk = 0; blk < num_blocks; ++blk) {
-                conv_rest<0, 1, false>(wlds, X, X, acc, w, lane);
-                between_convs<1, true>(wlds, acc, Y, b2, w, lane);
-                conv_rest<1, 0, true>(wlds, Y, X, acc, w, lane);
-                if (blk + 1 < num_blocks) between_convs<0, true>(wlds, acc, X, b1, w, lane);
-                else between_convs<0, false>(wlds, acc, X, b1, w, lane);
+                trunk_task<ROWS>(wlds, sbias, num_blocks, position(g_mine), hp, hv, 2 * half, lane);
+            } else {
+                trunk_task<ROWS / 2>(wlds, sbias, num_blocks, position(g_first), hp, hv, 2 * half, lane);
             }
             NTICK(1);
-            // 1x1 head convs as one MFMA per row: rows 0,1 of D = policy planes, row 2 = value plane, which
-            // land in the lanes q = 0 (registers 0..2) of each position
-            const bf16x8 ah = frag_ptr(wlds, OFF_HF, lane)[0];
-            const int p = lane & 15, x = p & 7, bl = (p >> 3) + 2 * half;
-#pragma unroll
-            for (int y = 0; y < ROWS; ++y) {
-                const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
-                const f32x4 d = MFMA16(ah, X[y], z4);
-                if (lane < 16 && x != 7) {
-                    const int cell = y * 7 + x;
-                    hp[bl * 96 + cell] = (__bf16)fmaxf(d[0] + sbias[96], 0.0f);
-                    hp[bl * 96 + 42 + cell] = (__bf16)fmaxf(d[1] + sbias[97], 0.0f);
-                    hv[bl * 48 + cell] = (__bf16)fmaxf(d[2] + sbias[98], 0.0f);
-                }
-            }
         }
 #ifdef AZ_EXP_TIMING
         if (worked) { NTICK(2); NCOUNT(6); } else NCOUNT(7);

@@ -127,10 +127,14 @@ def pack_c4_blob(model):
     parts = []
     with torch.no_grad():
         bias = torch.zeros(3, 32, dtype=torch.float64, device=dev)
-        # stem: one k-step, K index = tap*2 + plane (18 of 32 used)
+        # stem: one k-step, K index = 9 * kx + 3 * plane + ky (18 of 32 used: the order in which the kernel takes
+        # the window out of the bitboards)
         w, b = _fold_bn(model._cbr[0].weight, model._cbr[1])
         stem = torch.zeros(32, 32, dtype=torch.float64, device=dev)
-        stem[:C_, :18] = w.permute(0, 2, 3, 1).reshape(C_, 18)
+        for kx in range(3):
+            for plane in range(2):
+                for ky in range(3):
+                    stem[:C_, 9 * kx + 3 * plane + ky] = w[:, plane, ky, kx]
         parts.append(_trunk_frags(stem))
         bias[0, :C_] = b
         if len(model._tower):

@@ -7,7 +7,7 @@ OUT=${1:-gpurun_out/profiles_raw}
 mkdir -p "$OUT"
 ROOT=$(pwd)
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
-BENCH="bench.py --no-cpu-baseline --steps 3 --warmup 1"
+BENCH="bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1"
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_net" -- python3 $BENCH > "$OUT/bench_net.log" 2>&1
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_net_stepwise" -- python3 $BENCH --stepwise > "$OUT/bench_net_stepwise.log" 2>&1
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_net_cache" -- python3 $BENCH --eval-cache-log2 24 > "$OUT/bench_net_cache.log" 2>&1
