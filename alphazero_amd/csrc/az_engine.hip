@@ -846,9 +846,7 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
 #endif
     search(F_{}, T_{});
     for (int sim = 0; sim < num_sims; ++sim) {
-        // the planes of the head phase and the task list start every simulation as zeros
-        for (int i = tid; i < 8 * PW_BYTES / 16; i += NTHREADS)
-            reinterpret_cast<uint4*>(scr + S_PW)[i] = make_uint4(0, 0, 0, 0);
+        // the task list starts every simulation empty
         if (tid < 8 * MAXIT * 2) tlist[tid] = 0;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");        // leaves written by the search lanes
         __syncthreads();

@@ -44,18 +44,20 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define S_PW (S_BP + 256)                     // per-wave head scratch, PW_BYTES each:
 #define PW_HP 0                               //   bf16 [4][96] policy planes, k = ch*42 + cell
 #define PW_HV 768                             //   bf16 [4][48] value plane
-#define PW_BYTES 1152                         // all 8 together are reused as float [32][64] logits + [8][32] value sums
+#define PW_BYTES 1152                         // (the k-padding of the planes is zeroed once per launch and never written)
 #define MAXIT 8                               // wave-tasks per wave per launch (n <= 32768)
 #define S_TL (S_PW + 8 * PW_BYTES)            // int [8 waves][MAXIT][2] leaf index of each board
 #define S_WT (S_TL + 8 * MAXIT * 2 * 4)       // int [16] scan scratch
 #define S_HG (S_WT + 64)                      // int [32] leaf index of each head column
 #define S_LBB (S_HG + 128)                    // uint64 [64][2] leaf positions of the workgroup's own games (kernels
                                               // that produce the leaves themselves put them here)
+#define S_LG (S_LBB + 1024)                   // float [32 boards][64] policy logits, then [8 waves][32] value partial sums
+#define S_END (S_LG + 32 * 64 * 4 + 8 * 32 * 4)
 #ifdef AZ_EXP_TIMING
-#define S_DBG (S_LBB + 1024)                   // unsigned long long [8 waves][8] cycle counters (tuning builds only)
+#define S_DBG S_END                   // unsigned long long [8 waves][8] cycle counters (tuning builds only)
 #define S_BYTES (S_DBG + 512)
 #else
-#define S_BYTES (S_LBB + 1024)
+#define S_BYTES S_END
 #endif
 
 // blob layout (bytes); must match alphazero_amd/net.py
@@ -379,8 +381,8 @@ __device__ __forceinline__ void net_rounds(const uint8_t* blob, int num_blocks, 
     const float* sbp = reinterpret_cast<const float*>(scr + S_BP);
     const int* mylist = tlist + wave * MAXIT * 2;
     int* hgl = reinterpret_cast<int*>(scr + S_HG);                 // leaf of each of the 32 head columns
-    float* lg = reinterpret_cast<float*>(scr + S_PW);              // [32 boards][64] logits, over the planes
-    float* vpart = reinterpret_cast<float*>(scr + S_PW + 32 * 64 * 4);   // [8 waves][32 boards] value partial sums
+    float* lg = reinterpret_cast<float*>(scr + S_LG);              // [32 boards][64] logits
+    float* vpart = reinterpret_cast<float*>(scr + S_LG + 32 * 64 * 4);   // [8 waves][32 boards] value partial sums
     for (int round = 0; round < nrounds; ++round) {
         int hg0 = -1, hg1 = -1, hg2 = -1, hg3 = -1;
 #ifdef AZ_EXP_TIMING
@@ -455,7 +457,6 @@ __device__ __forceinline__ void net_rounds(const uint8_t* blob, int num_blocks, 
                 pacc = MFMA(a, *reinterpret_cast<const bf16x8*>(chp + 16 * s + 8 * hh), pacc);
             }
         }
-        __syncthreads();                                   // all planes consumed: logits may overwrite them
         if (hl < 32) vpart[hw * 32 + c] = part;
         if (hw < 2) {
 #pragma unroll
@@ -492,12 +493,8 @@ __device__ __forceinline__ void net_rounds(const uint8_t* blob, int num_blocks, 
             if (gidx >= 0) v_out[gidx] = tanhf(sv + sbias[99]);
         }
         NTICK(4);
-        if (round + 1 < nrounds) {
-            // the planes (and their k-padding) must read as zero again before the next round fills them
-            __syncthreads();
-            for (int i = tid; i < 8 * PW_BYTES / 16; i += NTHREADS)
-                reinterpret_cast<uint4*>(scr + S_PW)[i] = make_uint4(0, 0, 0, 0);
-            __syncthreads();
-        }
+        // The next round may start at once.  Its plane stores come after this round's barrier above, which every
+        // wave passed after its last plane read; planes of board slots without a leaf keep stale (finite) values
+        // whose results nobody reads; the planes' k-padding is never written and stays zero.
     }
 }
