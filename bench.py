@@ -323,8 +323,14 @@ def main():
         local = 0
     if args.gpus > 1 and world != args.gpus:
         sys.exit(f'bench.py: --gpus {args.gpus} but the launcher started {world} ranks')
-    if world > 1:
+    # AZ_BENCH_FORCE_DIST=1: run the multi-rank code path (RCCL process group, weight broadcast, record gather,
+    # barrier-bracketed timing) even with a single rank -- a check of the collectives on a one-GPU box
+    multi = world > 1 or os.environ.get('AZ_BENCH_FORCE_DIST') == '1'
+    if multi:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29531')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         torch.cuda.set_device(local)
         if rehearse:
             dist.init_process_group('gloo')
@@ -332,7 +338,7 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device('cuda', local))
     else:
         torch.cuda.set_device(0)
-    dev = torch.device('cuda', local if world > 1 else 0)
+    dev = torch.device('cuda', local if multi else 0)
     G, S = args.games, args.sims
 
     eng = E.SelfPlayEngine(E._lib.GAME_C4, G, S, exploration_depth=4, reuse_search_tree=True,
@@ -380,14 +386,14 @@ def main():
             eng.begin_move_uniform()
             timed(lambda: eng.run_sims_uniform(S), tree_ev, measure)
         else:
-            if world > 1 and packed_wire:
+            if multi and packed_wire:
                 # RCCL weight broadcast replaces model_server.latest() (model_server.py:32-40): the
                 # publishing rank packs its module once, the kernel-ready buffer travels, receivers
                 # evaluate from where it lands
                 if rank == 0:
                     fused.load_module(net)
                 broadcast_packed(fused, step_no[0] + 1, src=0)
-            elif world > 1:
+            elif multi:
                 from alphazero_amd.distributed import broadcast_model
                 broadcast_model(net, 1, src=0)
                 if args.net_impl == 'hip':
@@ -420,7 +426,7 @@ def main():
         # finished games are handed over every move (selfplay.py:41): on one GPU to the host, as the
         # reference's dataset sink wants them; with several ranks they stay in device memory and are
         # gathered on the replay rank over RCCL (replaces replay_buffer.py:28-47)
-        if world > 1:
+        if multi:
             recs, head = eng.take_finished_device()
             got, flags = gather_records_device(recs, head, dst=0)
             assert flags == 0 or args.allow_pool_errors, f'engine error bits {flags}'
@@ -429,7 +435,7 @@ def main():
             eng.drain_finished_bytes()
 
     def sync_all():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -456,14 +462,14 @@ def main():
     elapsed = time.perf_counter() - t0
     st1 = eng.stats()
     hits = (eng.eval_cache_hits() - hits0) if use_cache else 0
-    if fused_move and world == 1:
+    if fused_move and not multi:
         # untimed, single-GPU runs only: two moves through the per-simulation kernels, for their own durations (the search
         # kernel against HBM, the network kernel against the matrix cores)
         stepwise_now[0] = True
         for _ in range(2):
             one_step(True)
         torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -498,11 +504,11 @@ def main():
                    'eval_cache_log2': args.eval_cache_log2 if use_cache else 0,
                    'eval_cache_hit_rate': hits / max(evals, 1),
                    'games_finished': st1['games'] - st0['games'],
-                   'exchange': None if world == 1 else
+                   'exchange': None if not multi else
                    ('per step: broadcast_packed (kernel-ready weights, one in-place broadcast) + '
                     'gather_records_device (records device to device)' if packed_wire else
                     'per step: broadcast_model + gather_records_device'),
-                   'records_gathered_on_rank0': finished_on_dst[0] if world > 1 else None},
+                   'records_gathered_on_rank0': finished_on_dst[0] if multi else None},
     }
     if rank == 0:
         def avg_ms(pairs):
@@ -562,7 +568,7 @@ def main():
             out['roofline'] = {'kernel': 'k_run_uniform<GameC4>', 'bound': 'hbm', 'achieved': gbs,
                                'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
                                'traffic': None, 'avg_launch_ms': ms, 'bytes_per_sim': bps}
-        if world == 1 and fused_move and not args.no_extras:
+        if not multi and fused_move and not args.no_extras:
             from alphazero_amd.net import FusedC4NetF32
             f32 = FusedC4NetF32(net, dev)
             # (a) the same self-play loop with the fp32 parity kernel evaluating every leaf (stepwise calls)
@@ -652,7 +658,7 @@ def main():
                                                        're-pack of the weights for the self-play kernels'},
                 'window_states': len(window), 'note': 'one GPU; with N ranks the records are gathered on the trainer rank '
                                                       'and the packed weights broadcast (see config.exchange)'}
-        if not args.no_cpu_baseline and world == 1:      # the host-CPU baseline is timed at N = 1 only
+        if not args.no_cpu_baseline and not multi:      # the host-CPU baseline is timed at N = 1 only
             logical, physical = physical_cores()
             workers = cpu_share()
             pps, sps, npos, wall = cpu_baseline(args.model, S, args.cpu_seconds, workers)
@@ -671,7 +677,7 @@ def main():
                                              f'{workers} independent single-game workers, one core and one net call '
                                              f'per leaf each, model {args.model}'}
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -123,3 +123,19 @@ def test_bench_starts_two_ranks_by_itself():
     out = json.loads(line)
     assert out['n_gpus'] == 2 and out['steps'] == 3 and 'rehearsal' in out
     assert out['value'] > 0 and out['config']['records_gathered_on_rank0'] > 0
+
+
+def test_bench_exchange_path_over_rccl_with_one_rank():
+    """The multi-rank code path of bench.py on the real backend (RCCL: process group with a device id, packed
+    weight broadcast, head all_gather, record gather, barrier and max-reduce of the time), forced with a single
+    rank because this box has one GPU."""
+    env = dict(os.environ, AZ_BENCH_FORCE_DIST='1', MASTER_PORT=str(29600 + os.getpid() % 300))
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'AZ_BENCH_REHEARSE'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--games', '512', '--sims', '32',
+           '--mix-moves', '30', '--preroll', '2', '--steps', '3', '--warmup', '1', '--no-cpu-baseline']
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=150)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith('{')][-1])
+    assert out['n_gpus'] == 1 and out['config']['exchange'].startswith('per step: broadcast_packed')
+    assert out['config']['records_gathered_on_rank0'] > 0 and out['value'] > 0
