@@ -83,6 +83,7 @@ SIGNATURES = {
     'az_c4net128_workspace_bytes': (C.c_long, [C.c_int32]),
     'az_c4net128_bf16_forward': (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P, _P, _P, _P]),
     'az_c4net_f32_forward': (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P, _P]),
+    'az_c4_move_fused_max_games': (C.c_int, [_P]),
     'az_c4_move_fused': (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, _P]),
     'az_c4_move_fused_static': (C.c_int, [_P, _P, C.c_int32, _P]),
     'az_loss_fwd_bwd': (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P]),

@@ -1503,6 +1503,8 @@ static int fused_launch(az_engine* e, const uint8_t* blob, int32_t num_blocks, u
     return 0;
 }
 
+int az_c4_move_fused_max_games(const az_engine* e) { return e ? FUSED_MAX_GPW * e->num_cus : -1; }
+
 int az_c4_move_fused(az_engine* e, const uint8_t* blob, int32_t num_blocks, uint64_t* leaf_bb, int32_t* leaf_info,
                      float* p, float* v, void* stream) {
     if (!e || !blob || !leaf_bb || !leaf_info || !p || !v) return az_fail("null argument");

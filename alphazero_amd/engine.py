@@ -138,6 +138,10 @@ class SelfPlayEngine:
         check(self.lib.az_sim_step(self.h, ptr(p), ptr(v), ptr(self.leaf_bb), ptr(self.leaf_info), self._stream()))
         return self.leaf_bb, self.leaf_info
 
+    def fused_max_games(self):
+        """Largest engine that move_fused accepts on this device (64 games per compute unit)."""
+        return int(self.lib.az_c4_move_fused_max_games(self.h))
+
     def move_fused(self, net):
         """All S simulations of the move in one launch with a FusedC4Net (after begin_move / apply_root)."""
         if self._pv is None:

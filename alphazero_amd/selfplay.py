@@ -87,7 +87,8 @@ class SelfPlayWorker:
         # Connect Four with the <= 32-channel network: a whole move's simulations run in one launch
         # (az_c4_move_fused)
         from .net import FusedC4Net as _F
-        self._fused_move = isinstance(self._fused, _F) and evaluator is None and self.num_games <= 16384
+        self._fused_move = (isinstance(self._fused, _F) and evaluator is None
+                            and self.num_games <= self.engine.fused_max_games())
         if self._fused is not None and not self._fused_move and self.num_games > 32768:
             raise ValueError('the HIP network kernels take at most 32768 leaves per call: num_games <= 32768')
         self._version = 0

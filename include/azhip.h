@@ -270,10 +270,13 @@ int  az_c4net128_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uin
  * az_apply_root and az_choose_and_advance).  A workgroup owns its games for the whole move: search
  * step, network for those games' leaves, search step, ... with workgroup barriers only.  blob as for
  * az_c4net_bf16_forward; leaf_bb / leaf_info / p / v are the engine-sized DEVICE buffers of the
- * stepwise calls (used as scratch between the phases).  Up to 16384 games per engine; the evaluation
+ * stepwise calls (used as scratch between the phases).  Up to az_c4_move_fused_max_games() games per engine (16384 on an
+ * MI355X); the evaluation
  * cache is used when enabled.  Results are bit-identical to the stepwise loop with az_c4net_bf16_forward. */
 int  az_c4_move_fused(az_engine* e, const uint8_t* blob, int32_t num_blocks, uint64_t* leaf_bb,
                       int32_t* leaf_info, float* p, float* v, void* stream);
+/* largest engine (games) az_c4_move_fused accepts on the engine's device: 64 games per compute unit */
+int  az_c4_move_fused_max_games(const az_engine* e);
 
 /* az_c4_move_fused without its four staging arguments and without any allocation.  No counterpart in the
  * reference; for callers that cannot allocate device memory or pass a workspace: code under HIP graph capture,
