@@ -2,16 +2,13 @@
 //
 // The 10x128 network (alphazero/models.py:70-87 with block_channels = 128) has 295 KB of bf16
 // weights per 3x3 conv: they fit neither registers nor LDS, so unlike the 32-channel kernel
-// (az_net.hip) the weights stream from L2 while the activations of six boards stay in LDS for the
-// whole residual tower.  Per conv the algorithmic work is 2*9*128*128*42 = 12.4 MFLOP per leaf.
+// (az_net.hip) the weights stream from L2 through LDS while the activations of a wave's two boards
+// stay in registers for the whole residual tower.  Per conv the algorithmic work is
+// 2*9*128*128*42 = 12.4 MFLOP per leaf.
 //
 // Three launches: stem (bitboards -> bf16 activations in HBM), tower (in place), heads.
-// Activation tensor: [board][42 cells, cell = 7*row + column][128 ch] bf16, dense.  The tower keeps
-// the same dense rows in LDS: 6 boards = 252 rows fill 8 MFMA tiles of 32 positions with 4 idle
-// rows, and a 3x3 tap that leaves the board reads a shared all-zero row instead (a per-lane select
-// from a 9-bit validity mask), so no matrix-core work is spent on padding.
-// D[co][pos] orientation puts 4 consecutive channels of one position in 4 registers: the epilogue
-// (bias, residual, ReLU, bf16) moves 8 bytes per lane.
+// Activation tensor: [board][42 cells, cell = 7*row + column][128 ch] bf16, dense, channels in
+// their natural order.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -19,19 +16,13 @@
 #include "az_host.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define CH 128
-#define GB 6                        // boards per workgroup
+#define GB 8                        // boards per tower workgroup (the activation tensor is padded to whole workgroups)
 #define BPOS 42                     // positions per board
-#define NROW (GB * BPOS)            // 252 real rows per slab
-#define ZROW0 256                   // 16 all-zero rows, one per LDS slot residue (row mod 16)
-#define ROWB 272                    // LDS row stride in bytes: 256 + 16 (17 slots of 16 B, odd)
-#define NT 512
 
 // blob layout (bytes); must match alphazero_amd/net.py pack_c4_blob_128
-#define G_W 0                                        // bf16 [2 convs][9 taps][4 co tiles][8 k-steps][64 lanes][8]
+#define G_W 0                                        // bf16 [2 convs][4 groups][4 chunks][9 taps][2 halves][64 lanes][8]
 #define G_STEM (G_W + 2 * 9 * CH * CH * 2)           // f32 [18][128]  k = tap*2 + plane
 #define G_BIAS (G_STEM + 18 * CH * 4)                // f32 [3][128]   stem, c1, c2
 #define G_HW (G_BIAS + 3 * CH * 4)                   // f32 [3][128]   1x1 heads: policy 0, 1, value
@@ -43,8 +34,6 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define G_W2 (G_B1 + 256 * 4)                        // f32 [256]
 #define G_B2 (G_W2 + 256 * 4)                        // f32 [4]
 #define G_BLOB_BYTES (G_B2 + 16)
-
-#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
 // bf16(ReLU(a)), bf16(ReLU(b)) packed in one dword: convert first, then clamp the two bit patterns
 // as signed 16-bit integers (negative floats, -0 included, are negative integers)
@@ -154,227 +143,290 @@ __global__ void __launch_bounds__(256) k_stem128(const uint8_t* __restrict__ blo
     reinterpret_cast<bf16x8*>(dst)[1] = hi;
 }
 
-// ---- residual tower: 2 * num_blocks 3x3 convs 128 -> 128, activations resident in LDS ----------
-// Workgroup = 8 waves, 6 boards.  Two activation slabs live in LDS for the whole tower: the first
-// conv of a block reads slab X and writes slab Y, the second reads Y, adds the block input (still in
-// X) and overwrites X in place -- HBM sees one read and one write of the activations per tower, not
-// per conv.  Wave (wc, wp) owns channels [32 wc, 32 wc + 32) of rows [128 wp, 128 wp + 128): four
-// accumulators fed by one weight fragment.  Weights never touch LDS: they are stored in fragment
-// order [conv][tap][32-channel tile][k-step][lane][8 bf16] and every lane reads its 16 bytes
-// straight from L2 one tap ahead of use, alternating between two register buffers; the prefetch
-// runs across conv boundaries, so the only bubble per conv is the epilogue and its barrier.
-// The 18 taps of a block are unrolled, so tap geometry, buffer roles and epilogue kind are static.
+// ---- residual tower: 2 * num_blocks 3x3 convs 128 -> 128, activations resident in REGISTERS ------
+// A wave (one per SIMD, up to 512 registers) owns two boards for the whole tower.  Tiles, operand layout and
+// the tricks are those of the 32-channel trunk (az_net_dev.h): a tile is one board row of both boards (16
+// positions, the eighth cell of each row is a zero pad), contractions are v_mfma_f32_16x16x32_bf16 with one
+// 32-channel chunk of a tap per k-step, dy taps read the neighbouring row's register fragment, dx taps read the
+// row shifted by one lane (DPP, zero fill), output channels are permuted inside each group of 32 so that an
+// accumulator lands in the next layer's operand layout (lane-local ReLU / bf16 epilogue), the pad cell is kept at
+// zero by a -1e30 bias, and the residual is an identity "tap" on the matrix cores.  With 128 channels a tensor of
+// two boards is 4 chunks x 6 rows = 24 fragments (96 registers); X (block input) and Y (first conv's output)
+// both stay in registers, 48 registers accumulate one group of 32 output channels at a time.
+// Weights (295 KB per conv) stream L2 -> LDS -> registers: the 72 KB of one output group ([tap][chunk][half]
+// fragments, contiguous in the blob) are fetched by the whole workgroup into the idle half of a double buffer
+// while the other half is being consumed, one workgroup barrier per group (every 396 MFMAs per wave); the four
+// waves of a workgroup (eight boards) share every fetched byte.  HBM sees one read and one write of the
+// activations per tower.
 #define CONV_BYTES (9 * CH * CH * 2)
-#define NTILE 4
-#define SLAB_ROWS (ZROW0 + 16)           // 252 real rows, 4 landing rows for the idle lanes, 16 zero rows
-#undef SLAB_BYTES
-#define SLAB_BYTES (SLAB_ROWS * ROWB)
-#define BIAS_OFF (2 * SLAB_BYTES)
+#define TB GB                        // boards per workgroup: 4 waves x 2
+#define TROWS 6                      // board rows = tiles of a wave's two boards
+#define NT 256
+#define CHUNK_BYTES (4 * 9 * 2 * 1024)          // one output group of one conv: [chunk 4][tap 9][half 2][64][8] bf16
+#define HALF_BYTES (CHUNK_BYTES / 2)            // input chunks 0, 1 | 2, 3: each within reach of a ds_read immediate offset
+#define T_BIAS_OFF (2 * CHUNK_BYTES)            // f32 [2][128] conv biases
+#define T_LDS_BYTES (T_BIAS_OFF + 2 * CH * 4)
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+#define PAD_BIAS (-1.0e30f)
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-struct TowerCtx {
-    const uint8_t* wts;
-    uint8_t* lds;
-    int qrow[NTILE];     // byte offset of the lane's row in a slab, per tile
-    int vmask[NTILE];    // bit k: tap k of that row stays on the board (0 for idle lanes)
-    int wc, h, lane;
+template <int CTRL>
+__device__ __forceinline__ bf16x8 dpp_frag(const bf16x8& v) {
+    const uint4 u = __builtin_bit_cast(uint4, v);
+    uint4 r;
+    r.x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u.x, CTRL, 0xF, 0xF, true);
+    r.y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u.y, CTRL, 0xF, 0xF, true);
+    r.z = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u.z, CTRL, 0xF, 0xF, true);
+    r.w = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u.w, CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(bf16x8, r);
+}
+// the row as seen one cell to the left (lane p reads lane p - 1: row_shr:1) or to the right (row_shl:1)
+template <bool LEFT>
+__device__ __forceinline__ bf16x8 shift_cell(const bf16x8& v) { return dpp_frag<LEFT ? 0x111 : 0x101>(v); }
+
+struct Bias2 { f32x4 h0, h1; };
+__device__ __forceinline__ Bias2 lane_bias(const uint8_t* lds, uint32_t group_off, int lane) {
+    const int q = lane >> 4;
+    const float* bias = reinterpret_cast<const float*>(lds + group_off);
+    Bias2 b;
+    b.h0 = *reinterpret_cast<const f32x4*>(bias + 8 * q);
+    b.h1 = *reinterpret_cast<const f32x4*>(bias + 8 * q + 4);
+    if ((lane & 7) == 7) {
+        const f32x4 pad = {PAD_BIAS, PAD_BIAS, PAD_BIAS, PAD_BIAS};
+        b.h0 = pad; b.h1 = pad;
+    }
+    return b;
+}
+
+// An LDS byte offset the compiler must keep in one register and may not fold into the absolute addresses
+// behind it: a ds_read immediate reaches 64 KB, the weight buffers span 144 KB, and every address past the reach
+// would otherwise get (and keep, hoisted out of the block loop) a register of its own.
+__device__ __forceinline__ uint32_t opaque(uint32_t off) {
+    asm volatile("" : "+v"(off));
+    return off;
+}
+
+// both halves' weight fragments of tap (KY, KX) of input chunk KC; `wb` = this lane's offset in the half buffer
+struct WPair { bf16x8 a0, a1; };
+template <int KY, int KX, int KC>
+__device__ __forceinline__ WPair wload(const uint8_t* lds, uint32_t wb) {
+    const bf16x8* wf = reinterpret_cast<const bf16x8*>(lds + wb) + (((KC & 1) * 9 + KY * 3 + KX) * 2) * 64;
+    WPair w;
+    w.a0 = wf[0]; w.a1 = wf[64];
+    return w;
+}
+
+template <int KY>
+__device__ __forceinline__ void tap_rows(f32x4 (&acc)[TROWS][2], const bf16x8 (&s)[TROWS], const WPair& w) {
+#pragma unroll
+    for (int y = 0; y < TROWS; ++y) {
+        const int yy = y + KY - 1;
+        if (yy < 0 || yy >= TROWS) continue;
+        acc[y][0] = MFMA16(w.a0, s[yy], acc[y][0]);
+        acc[y][1] = MFMA16(w.a1, s[yy], acc[y][1]);
+    }
+}
+
+// The workgroup's copy of the next group's weights, global -> registers -> LDS, in STAGE_BATCHES bursts spread
+// over the 36 tap regions of the group being computed: a batch (6 x 16 bytes per thread) is fetched at the start
+// of its third of the group and written to LDS at the start of the next third (the last one after the last
+// region), which gives the fetch 12 regions (about 2k cycles) to arrive and costs 24 registers.  Measured
+// alternatives: one piece per region (trickle) and one burst per group are 5 % slower, LDS-DMA loads
+// (global_load_lds_dwordx4, no registers) 1.5 % faster.  `src` is uniform or null,
+// `dst_off` = opaque(buffer offset + 16 * tid).
+#define NSTAGE (CHUNK_BYTES / 16 / NT)           // 18 pieces per thread and group
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+#define STAGE_BATCHES 3
+#define STAGE_PER (NSTAGE / STAGE_BATCHES)
+struct Stage {
+    u32x4 v[STAGE_PER];
+    const uint8_t* src;
+    uint32_t tid16, dst_off;
 };
-
-template <int CONV, int TAP>
-__device__ __forceinline__ void load_wfrag(uint4 (&buf)[8], const TowerCtx& c) {
-    // uniform base + one 32-bit lane offset (kept opaque so that 18 taps of 64-bit addresses are not
-    // precomputed outside the block loop); the k-step is the instruction's immediate offset
-    const uint8_t* base = c.wts + (size_t)CONV * CONV_BYTES + TAP * (4 * 8 * 64 * 16);
-    uint32_t voff = (uint32_t)(c.wc * 8 * 64 + c.lane) * 16;
-    asm volatile("" : "+v"(voff));
+// called at the start of every region; REGION == 36: after the last one
+template <int REGION>
+__device__ __forceinline__ void stage_tick(Stage& st, uint8_t* lds) {
+    if (!st.src) return;
+    if (REGION % (36 / STAGE_BATCHES) != 0) return;
+    constexpr int B = REGION / (36 / STAGE_BATCHES);
+    if (B > 0) {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) buf[s] = *reinterpret_cast<const uint4*>(base + (s >> 2) * 4096 + voff + (s & 3) * 1024);
-}
-
-template <int TAP>
-__device__ __forceinline__ void tap_offsets(int (&off)[NTILE], const TowerCtx& c) {
-    // An off-board tap reads the zero row with the same residue mod 16 as the row it replaces: the
-    // 16 lanes of a ds_read_b128 group then still fall on 16 different 16-byte slots (row stride =
-    // 17 slots), which one shared zero row would break for every group with a border cell.
-    // (Tiles start at multiples of 32 rows, so that residue is the same for the lane's four tiles.)
-    constexpr int delta = (TAP / 3 - 1) * 7 + (TAP % 3 - 1);
-    int col = c.lane;
-    asm volatile("" : "+v"(col));        // recomputed per tap: hoisting 18 taps of offsets out of the block loop would spill
-    const int zoff = (ZROW0 + ((col + delta) & 15)) * ROWB;
+        for (int j = 0; j < STAGE_PER; ++j)
+            *reinterpret_cast<u32x4*>(lds + st.dst_off + ((B - 1) * STAGE_PER + j) * (NT * 16)) = st.v[j];
+    }
+    if (B < STAGE_BATCHES) {
 #pragma unroll
-    for (int t = 0; t < NTILE; ++t) {
-        int m = c.vmask[t];
-        asm volatile("" : "+v"(m));
-        off[t] = ((m >> TAP) & 1) ? c.qrow[t] + delta * ROWB : zoff;
+        for (int j = 0; j < STAGE_PER; ++j)
+            st.v[j] = *reinterpret_cast<const u32x4*>(st.src + (B * STAGE_PER + j) * (NT * 16) + st.tid16);
     }
 }
 
-// One tap = 8 k-steps of 4 MFMAs.  Activation fragments are read one k-step ahead of the MFMAs that
-// consume them (b0 / b1 alternate), and the last k-step already fetches the next tap's first
-// fragments, so an LDS round trip is never on the matrix pipe's critical path.  On entry b0 holds
-// k-step 0 of this tap.  Tap 0 starts the accumulators from zero; tap 8 ends with the epilogue
-// (bias, residual on the second conv of a block, ReLU, bf16, write to the other slab) and a barrier.
-template <int CONV, int TAP>
-__device__ __forceinline__ void tower_tap(f32x16 (&acc)[NTILE], const uint4 (&cur)[8], uint4 (&nxt)[8], bf16x8 (&b0)[NTILE],
-                                          const TowerCtx& c, bool more) {
-    constexpr bool SECOND = CONV == 1;
-    if (TAP < 8) load_wfrag<CONV, (TAP + 1) % 9>(nxt, c);
-    else if (more) load_wfrag<1 - CONV, 0>(nxt, c);
-    const uint8_t* src = c.lds + CONV * SLAB_BYTES + c.h * 16;
-    int off[NTILE], offn[NTILE];
-    tap_offsets<TAP>(off, c);
-    if (TAP < 8) tap_offsets<(TAP + 1) % 9>(offn, c);
-    bf16x8 b1[NTILE];
+// the nine taps of input chunk KC into the accumulators of the current output group.  On entry w = weights of
+// the centre tap of chunk KC, on exit w = those of chunk KC + 1 (or, after the last chunk, whatever `last` loads).
+template <int KC, class LastLoad>
+__device__ __forceinline__ void chunk_taps(uint8_t* lds, uint32_t wb, const bf16x8 (&in)[TROWS],
+                                           f32x4 (&acc)[TROWS][2], const Bias2& bias, WPair& w, Stage& st, LastLoad last) {
+    WPair n;
+    bf16x8 sl[TROWS], sr[TROWS];
+    // centre column; the first tap of the first chunk starts the accumulators from the bias
+    n = wload<0, 1, KC>(lds, wb);
 #pragma unroll
-    for (int s = 0; s < 8; s += 2) {
-        bf16x8 a;
-#pragma unroll
-        for (int t = 0; t < NTILE; ++t) b1[t] = *reinterpret_cast<const bf16x8*>(src + off[t] + (s + 1) * 32);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_memcpy(&a, &cur[s], 16);
-        if (TAP == 0 && s == 0) {
-            const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int t = 0; t < NTILE; ++t) acc[t] = MFMA(a, b0[t], zero);
+    for (int y = 0; y < TROWS; ++y) {
+        if (KC == 0) {
+            acc[y][0] = MFMA16(w.a0, in[y], bias.h0);
+            acc[y][1] = MFMA16(w.a1, in[y], bias.h1);
         } else {
-#pragma unroll
-            for (int t = 0; t < NTILE; ++t) acc[t] = MFMA(a, b0[t], acc[t]);
+            acc[y][0] = MFMA16(w.a0, in[y], acc[y][0]);
+            acc[y][1] = MFMA16(w.a1, in[y], acc[y][1]);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (s + 2 < 8) {
-#pragma unroll
-            for (int t = 0; t < NTILE; ++t) b0[t] = *reinterpret_cast<const bf16x8*>(src + off[t] + (s + 2) * 32);
-        } else if (TAP < 8) {
-#pragma unroll
-            for (int t = 0; t < NTILE; ++t) b0[t] = *reinterpret_cast<const bf16x8*>(src + offn[t]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_memcpy(&a, &cur[s + 1], 16);
-#pragma unroll
-        for (int t = 0; t < NTILE; ++t) acc[t] = MFMA(a, b1[t], acc[t]);
-        __builtin_amdgcn_sched_barrier(0);
     }
-    if (TAP < 8) return;
+    w = n; stage_tick<9 * KC + 1>(st, lds); FENCE();
+    n = wload<2, 1, KC>(lds, wb); tap_rows<0>(acc, in, w);
+#pragma unroll
+    for (int y = 0; y < 3; ++y) sl[y] = shift_cell<true>(in[y]);
+    w = n; stage_tick<9 * KC + 2>(st, lds); FENCE();
+    n = wload<1, 0, KC>(lds, wb); tap_rows<2>(acc, in, w);
+#pragma unroll
+    for (int y = 3; y < TROWS; ++y) sl[y] = shift_cell<true>(in[y]);
+    w = n; stage_tick<9 * KC + 3>(st, lds); FENCE();
+    // window column 0; meanwhile the rows for window column 2
+    n = wload<0, 0, KC>(lds, wb); tap_rows<1>(acc, sl, w);
+    sr[0] = shift_cell<false>(in[0]); sr[1] = shift_cell<false>(in[1]);
+    w = n; stage_tick<9 * KC + 4>(st, lds); FENCE();
+    n = wload<2, 0, KC>(lds, wb); tap_rows<0>(acc, sl, w);
+    sr[2] = shift_cell<false>(in[2]); sr[3] = shift_cell<false>(in[3]);
+    w = n; stage_tick<9 * KC + 5>(st, lds); FENCE();
+    n = wload<1, 2, KC>(lds, wb); tap_rows<2>(acc, sl, w);
+    sr[4] = shift_cell<false>(in[4]); sr[5] = shift_cell<false>(in[5]);
+    w = n; stage_tick<9 * KC + 6>(st, lds); FENCE();
+    // window column 2
+    n = wload<0, 2, KC>(lds, wb); tap_rows<1>(acc, sr, w); w = n; stage_tick<9 * KC + 7>(st, lds); FENCE();
+    n = wload<2, 2, KC>(lds, wb); tap_rows<0>(acc, sr, w); w = n; stage_tick<9 * KC + 8>(st, lds); FENCE();
+    n = last(); tap_rows<2>(acc, sr, w); w = n; stage_tick<9 * KC + 9>(st, lds); FENCE();
+}
 
-    // epilogue: register r = channel 32*wc + (r&3) + 8*(r>>2) + 4*h of the lane's row
-    uint8_t* dst = c.lds + (SECOND ? 0 : SLAB_BYTES) + (32 * c.wc + 4 * c.h) * 2;
-    const float* bp = reinterpret_cast<const float*>(c.lds + BIAS_OFF) + CONV * CH + 32 * c.wc + 4 * c.h;
-    float4 bv[4];
+// a uniform byte offset the compiler recomputes where it is used instead of keeping every multiple live
+__device__ __forceinline__ uint32_t opaque_uniform(uint32_t off) {
+    asm volatile("" : "+s"(off));
+    return off;
+}
+
+// One group of 32 output channels of one conv: the four input chunks (the next group's weights trickle into
+// the other LDS buffer meanwhile, when `src` is not null), (RES) the identity tap over the residual's chunk,
+// ReLU / bf16 into `out`.
+template <bool RES>
+__device__ __forceinline__ void out_group(uint8_t* lds, uint32_t wb, const WPair& ident,
+                                          const bf16x8 (&in)[4][TROWS], const bf16x8 (&res)[TROWS],
+                                          bf16x8 (&out)[TROWS], const Bias2& bias, const uint8_t* src, uint32_t tid16,
+                                          uint32_t dst_off) {
+    f32x4 acc[TROWS][2];
+    Stage st;
+    st.src = src; st.tid16 = tid16; st.dst_off = dst_off;
+    const uint32_t wb2 = opaque(wb + HALF_BYTES);
+    WPair w = wload<1, 1, 0>(lds, wb);
+    stage_tick<0>(st, lds);
+    chunk_taps<0>(lds, wb, in[0], acc, bias, w, st, [&] { return wload<1, 1, 1>(lds, wb); });
+    chunk_taps<1>(lds, wb, in[1], acc, bias, w, st, [&] { return wload<1, 1, 2>(lds, wb2); });
+    chunk_taps<2>(lds, wb2, in[2], acc, bias, w, st, [&] { return wload<1, 1, 3>(lds, wb2); });
+    chunk_taps<3>(lds, wb2, in[3], acc, bias, w, st, [&] { return ident; });
+    if (RES) {
 #pragma unroll
-    for (int gq = 0; gq < 4; ++gq) bv[gq] = *reinterpret_cast<const float4*>(bp + 8 * gq);
-    uint2 r[NTILE][4];
-    if (SECOND) {
-#pragma unroll
-        for (int t = 0; t < NTILE; ++t)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) r[t][gq] = *reinterpret_cast<const uint2*>(dst + c.qrow[t] + 16 * gq);
-    }
-#pragma unroll
-    for (int t = 0; t < NTILE; ++t) {
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            float x0 = acc[t][4 * gq] + bv[gq].x, x1 = acc[t][4 * gq + 1] + bv[gq].y;
-            float x2 = acc[t][4 * gq + 2] + bv[gq].z, x3 = acc[t][4 * gq + 3] + bv[gq].w;
-            if (SECOND) {
-                x0 += __uint_as_float(r[t][gq].x << 16); x1 += __uint_as_float(r[t][gq].x & 0xFFFF0000u);
-                x2 += __uint_as_float(r[t][gq].y << 16); x3 += __uint_as_float(r[t][gq].y & 0xFFFF0000u);
-            }
-            *reinterpret_cast<uint2*>(dst + c.qrow[t] + 16 * gq) = make_uint2(relu_bf16x2(x0, x1), relu_bf16x2(x2, x3));
+        for (int y = 0; y < TROWS; ++y) {
+            acc[y][0] = MFMA16(w.a0, res[y], acc[y][0]);
+            acc[y][1] = MFMA16(w.a1, res[y], acc[y][1]);
         }
     }
-    __syncthreads();
-    if (more) {                                // first fragments of the next conv, from the slab just written
-        const uint8_t* src2 = c.lds + (SECOND ? 0 : SLAB_BYTES) + c.h * 16;
-        tap_offsets<0>(off, c);
 #pragma unroll
-        for (int t = 0; t < NTILE; ++t) b0[t] = *reinterpret_cast<const bf16x8*>(src2 + off[t]);
+    for (int y = 0; y < TROWS; ++y) {
+        const f32x4 c0 = acc[y][0], c1 = acc[y][1];
+        out[y] = __builtin_bit_cast(bf16x8, make_uint4(relu_bf16x2(c0[0], c0[1]), relu_bf16x2(c0[2], c0[3]),
+                                                       relu_bf16x2(c1[0], c1[1]), relu_bf16x2(c1[2], c1[3])));
     }
 }
 
-__global__ void __launch_bounds__(NT, 2)
-k_tower128(const uint8_t* __restrict__ wts /* fragment order, two convs */, const float* __restrict__ bias /* [3][128] */,
-           __bf16* __restrict__ act, int num_blocks, const int32_t* __restrict__ list, int nleaves) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // [2][SLAB_ROWS][ROWB], then f32 [2][128] biases
-    if ((int)blockIdx.x * GB >= boards_to_run(list, nleaves)) return;   // whole workgroup, before any barrier
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 31;
-    const int wp = wave >> 2;
-    TowerCtx c;
-    c.wts = wts; c.lds = lds; c.wc = wave & 3; c.h = lane >> 5; c.lane = lane;
+__global__ void __launch_bounds__(NT, 1)
+k_tower128(const uint8_t* __restrict__ wts /* [conv][group][tap][chunk][half] fragments */,
+           const float* __restrict__ bias /* [3][128] */, __bf16* __restrict__ act, int num_blocks,
+           const int32_t* __restrict__ list, int nleaves) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // two weight buffers, then f32 [2][128] biases
+    if ((int)blockIdx.x * TB >= boards_to_run(list, nleaves)) return;   // whole workgroup, before any barrier
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int p = lane & 15, q = lane >> 4, x = p & 7;
+    const bool cell = x != 7;
 
-    uint4 bufa[8], bufb[8];
-    load_wfrag<0, 0>(bufa, c);
-    if (tid < 2 * CH) reinterpret_cast<float*>(lds + BIAS_OFF)[tid] = bias[CH + tid];   // conv biases
+    // weights of the first group on their way while the activations are fetched
+    const uint32_t tid16 = (uint32_t)tid * 16, lane16 = (uint32_t)lane * 16;
+    u32x4 first[NSTAGE];
+#pragma unroll
+    for (int j = 0; j < NSTAGE; ++j) first[j] = *reinterpret_cast<const u32x4*>(wts + j * (NT * 16) + tid16);
+    if (tid < 2 * CH) reinterpret_cast<float*>(lds + T_BIAS_OFF)[tid] = bias[CH + tid];   // conv biases
 
-    // stage the six boards: 252 rows of 16 pieces of 16 B, contiguous in HBM; every load is issued
-    // before the first LDS write so the latencies overlap
-    uint4* gsl = reinterpret_cast<uint4*>(act + (size_t)blockIdx.x * NROW * CH);
+    // this lane's board and the two tensors; element (y, x, channel 32 kc + 8 q ..) of board b is 16 contiguous bytes
+    const size_t board = (size_t)blockIdx.x * TB + wave * 2 + (p >> 3);
+    __bf16* mine = act + (board * BPOS + x) * CH + 8 * q;
+    bf16x8 X[4][TROWS], Y[4][TROWS];
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+        for (int y = 0; y < TROWS; ++y) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (cell) v = *reinterpret_cast<const uint4*>(mine + (size_t)y * 7 * CH + 32 * kc);
+            X[kc][y] = __builtin_bit_cast(bf16x8, v);
+        }
+    // identity fragments: row r of half h is channel 8 (r / 4) + 4 h + r % 4 of the group
+    WPair ident;
     {
-        constexpr int TOTAL = NROW * 16;
-        constexpr int NLD = (TOTAL + NT - 1) / NT;
-        uint4 tmp[NLD];
+        const int r = lane & 15;
+        uint32_t d[2][4];
 #pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            const int i = tid + j * NT;
-            tmp[j] = i < TOTAL ? gsl[i] : make_uint4(0, 0, 0, 0);
-        }
+        for (int h = 0; h < 2; ++h) {
+            const int ch = 8 * (r >> 2) + 4 * h + (r & 3);
 #pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            const int i = tid + j * NT;
-            if (i < TOTAL) *reinterpret_cast<uint4*>(lds + (i >> 4) * ROWB + (i & 15) * 16) = tmp[j];
+            for (int i = 0; i < 4; ++i) {
+                const int k0 = 8 * q + 2 * i;
+                d[h][i] = (k0 == ch ? 0x3F80u : 0u) | (k0 + 1 == ch ? 0x3F800000u : 0u);
+            }
         }
-        // zero rows of both slabs: 2 x 16 rows x 16 pieces
-        *reinterpret_cast<uint4*>(lds + (tid >> 8) * SLAB_BYTES + (ZROW0 + ((tid >> 4) & 15)) * ROWB + (tid & 15) * 16) = make_uint4(0, 0, 0, 0);
+        ident.a0 = __builtin_bit_cast(bf16x8, make_uint4(d[0][0], d[0][1], d[0][2], d[0][3]));
+        ident.a1 = __builtin_bit_cast(bf16x8, make_uint4(d[1][0], d[1][1], d[1][2], d[1][3]));
     }
-
-    // this wave's four row tiles.  The four lanes past row 251 read zero rows for every tap and
-    // write their results to the landing rows 252..255, so the epilogue needs no lane mask.
+    {
+        const uint32_t to = opaque(tid16);
 #pragma unroll
-    for (int t = 0; t < NTILE; ++t) {
-        const int R = (wp * NTILE + t) * 32 + col;
-        const int o = R % BPOS, y = o / 7, x = o - 7 * y;
-        int m = 0;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-            m |= (yy >= 0 && yy < 6 && xx >= 0 && xx < 7) << tap;
-        }
-        c.qrow[t] = R * ROWB;
-        c.vmask[t] = R < NROW ? m : 0;
+        for (int j = 0; j < NSTAGE; ++j) *reinterpret_cast<u32x4*>(lds + to + j * (NT * 16)) = first[j];
     }
-    f32x16 acc[NTILE];
     __syncthreads();
-    bf16x8 b0[NTILE];
-    {
-        int off[NTILE];
-        tap_offsets<0>(off, c);
-#pragma unroll
-        for (int t = 0; t < NTILE; ++t) b0[t] = *reinterpret_cast<const bf16x8*>(lds + c.h * 16 + off[t]);
-    }
 
 #pragma unroll 1
     for (int blk = 0; blk < num_blocks; ++blk) {
         const bool more = blk + 1 < num_blocks;
-        tower_tap<0, 0>(acc, bufa, bufb, b0, c, true);
-        tower_tap<0, 1>(acc, bufb, bufa, b0, c, true);
-        tower_tap<0, 2>(acc, bufa, bufb, b0, c, true);
-        tower_tap<0, 3>(acc, bufb, bufa, b0, c, true);
-        tower_tap<0, 4>(acc, bufa, bufb, b0, c, true);
-        tower_tap<0, 5>(acc, bufb, bufa, b0, c, true);
-        tower_tap<0, 6>(acc, bufa, bufb, b0, c, true);
-        tower_tap<0, 7>(acc, bufb, bufa, b0, c, true);
-        tower_tap<0, 8>(acc, bufa, bufb, b0, c, true);
-        tower_tap<1, 0>(acc, bufb, bufa, b0, c, true);
-        tower_tap<1, 1>(acc, bufa, bufb, b0, c, true);
-        tower_tap<1, 2>(acc, bufb, bufa, b0, c, true);
-        tower_tap<1, 3>(acc, bufa, bufb, b0, c, true);
-        tower_tap<1, 4>(acc, bufb, bufa, b0, c, true);
-        tower_tap<1, 5>(acc, bufa, bufb, b0, c, true);
-        tower_tap<1, 6>(acc, bufb, bufa, b0, c, true);
-        tower_tap<1, 7>(acc, bufa, bufb, b0, c, true);
-        tower_tap<1, 8>(acc, bufb, bufa, b0, c, more);
+        // step s = conv * 4 + group uses buffer s & 1 and fetches the weights of step s + 1 into the other
+#define TOWER_STEP(S, RESFLAG, IN, RESCH, OUT)                                                              \
+        {                                                                                                   \
+            const uint8_t* src = ((S) < 7 || more) ? wts + opaque_uniform((((S) + 1) & 7) * CHUNK_BYTES) : nullptr; \
+            const Bias2 bs = lane_bias(lds, opaque(T_BIAS_OFF + (((S) >> 2) * CH + 32 * ((S) & 3)) * 4), lane); \
+            out_group<RESFLAG>(lds, opaque(((S) & 1) * CHUNK_BYTES + lane16), ident, IN, RESCH, OUT, bs, src, tid16, \
+                               opaque((((S) + 1) & 1) * CHUNK_BYTES + tid16));                              \
+            __syncthreads();                                                                                \
+        }
+        TOWER_STEP(0, false, X, X[0], Y[0])
+        TOWER_STEP(1, false, X, X[1], Y[1])
+        TOWER_STEP(2, false, X, X[2], Y[2])
+        TOWER_STEP(3, false, X, X[3], Y[3])
+        TOWER_STEP(4, true, Y, X[0], X[0])
+        TOWER_STEP(5, true, Y, X[1], X[1])
+        TOWER_STEP(6, true, Y, X[2], X[2])
+        TOWER_STEP(7, true, Y, X[3], X[3])
+#undef TOWER_STEP
     }
-
-    for (int i = tid; i < NROW * 16; i += NT)
-        gsl[i] = *reinterpret_cast<const uint4*>(lds + (i >> 4) * ROWB + (i & 15) * 16);
+    if (cell) {
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+            for (int y = 0; y < TROWS; ++y)
+                *reinterpret_cast<uint4*>(mine + (size_t)y * 7 * CH + 32 * kc) = __builtin_bit_cast(uint4, X[kc][y]);
+    }
 }
 
 // ---- heads: 1x1 convs, FCs, landing-cell gather, soft-max (vector ALU, fp32) ---------------------
@@ -477,7 +529,7 @@ int az_c4net128_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uint
     __bf16* t0 = reinterpret_cast<__bf16*>(workspace);
     int32_t* list = leaf_info ? reinterpret_cast<int32_t*>(static_cast<uint8_t*>(workspace) + act_bytes(n)) : nullptr;
     if (list) hipLaunchKernelGGL(k_compact128, dim3(1), dim3(1024), 0, st, leaf_info, (int)n, list);
-    const int lds = BIAS_OFF + 2 * CH * 4;
+    const int lds = T_LDS_BYTES;
     static std::atomic<unsigned long long> attr_done{0};
     if (int rc = az_set_kernel_lds(reinterpret_cast<const void*>(k_tower128), lds, attr_done)) return rc;
     const int ngroups = (n + GB - 1) / GB;

@@ -293,9 +293,15 @@ def pack_c4_blob_128(model):
                ph._fc.weight.double(), torch.cat([ph._fc.bias.double(), z(2)]),
                vh._fc[0].weight.double().t().contiguous(), vh._fc[0].bias.double(), vh._fc[2].weight.double(),
                torch.cat([vh._fc[2].bias.double().reshape(1), z(3)])]
-        # MFMA A-fragment order: [conv][tap][co tile][k-step][lane = h*32 + col][8], element j of a
-        # lane is W[co = 32*tile + col][ci = 16*step + 8*h + j]
-        wts = wts.reshape(2, 9, 4, 32, 8, 2, 8).permute(0, 1, 2, 4, 5, 3, 6)
+        # 16x16x32 A-fragment order: [conv][group of 32 co][chunk of 32 ci][tap][half][lane = 16 q + r][8], element
+        # j of a lane is W[co = 32 group + 8 (r // 4) + 4 half + r % 4][ci = 32 chunk + 8 q + j]: the row
+        # permutation inside a group makes an accumulator land in the next conv's operand layout
+        r = torch.arange(16, device=dev)
+        co = (32 * torch.arange(4, device=dev).view(4, 1, 1) + 4 * torch.arange(2, device=dev).view(1, 2, 1) +
+              (8 * (r // 4) + r % 4).view(1, 1, 16))                          # [group][half][r]
+        ci = torch.arange(128, device=dev).view(4, 4, 8)                       # [chunk][q][j]
+        wts = wts[:, :, co][:, :, :, :, :, ci]                                 # [conv][tap][group][half][r][chunk][q][j]
+        wts = wts.permute(0, 2, 5, 1, 3, 6, 4, 7)                              # [conv][group][chunk][tap][half][q][r][j]
         blob = torch.cat([wts.float().to(torch.bfloat16).contiguous().view(torch.uint8).reshape(-1)] +
                          [t.reshape(-1).float().contiguous().view(torch.uint8) for t in f32])
     assert blob.numel() == _lib.load().az_c4net128_blob_bytes(), blob.numel()
