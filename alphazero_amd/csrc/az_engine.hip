@@ -83,6 +83,8 @@ struct Dev {
     uint4*          cache;      // evaluation cache: 4 x 16 B per entry, or null
     uint32_t        cache_mask; // entries - 1
     unsigned long long* cache_hits;   // one counter per wavefront of the search grid (no atomics)
+    int32_t*        order;      // one-launch-per-move kernel: [G + 64] game of each workgroup slot, then [G] evaluation
+                                // counter of each game when its last such launch started
     double          alpha, eps, c_base, c_init;
     float           one_minus_eps;
     uint64_t        seed, uid_stride, first_uid;
@@ -636,10 +638,12 @@ __device__ __forceinline__ void backup_g(uint4* pool, int depth, const uint32_t*
 // batch of loads, so the dependent chain is: slot -> edges to back up -> root -> one line per level.
 // `path` is the group's scratch for (node, slot) per level: a row of an LDS stack, or the slot's own
 // path array in global memory (PATH_IN_SLOT), in which case nothing has to be copied for the next launch.
+// `sel` (when DO_SELECT): a run-time switch, the same for all lanes of a group, that turns this call's select
+// off.  Returns the kind of the leaf the call ends with (AZ_LEAF_NONE without a select).
 template <class GM, int GS, bool DO_EXPAND, bool DO_SELECT, bool PATH_IN_SLOT = false>
-__device__ __forceinline__ void sim_step_game(const Dev& E, const float* p, const float* v, uint64_t* leaf_bb,
-                                              int32_t* leaf_info, int g, int lane, int sub, Slot* s, uint4* pool,
-                                              uint32_t* path, int wave_id, uint64_t* lds_leaf = nullptr) {
+__device__ __forceinline__ int sim_step_game(const Dev& E, const float* p, const float* v, uint64_t* leaf_bb,
+                                             int32_t* leaf_info, int g, int lane, int sub, Slot* s, uint4* pool,
+                                             uint32_t* path, int wave_id, uint64_t* lds_leaf = nullptr, bool sel = true) {
     using G_ = Grp<GS>;
     constexpr int AS = GM::A + 1;
     const uint4* sh = reinterpret_cast<const uint4*>(s);
@@ -708,10 +712,10 @@ __device__ __forceinline__ void sim_step_game(const Dev& E, const float* p, cons
         sims += 1; evals += 1;
         kind = AZ_LEAF_NONE;
     }
-    if (DO_EXPAND && DO_SELECT) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // own stores before re-reading nodes
+    if (DO_EXPAND && DO_SELECT && sel) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // own stores before re-reading nodes
 
     int depth = 0;
-    if (DO_SELECT) {
+    if (DO_SELECT && sel) {
         float vterm;
         uint4 cq = make_uint4(0u, 0u, 0u, 0u);
         const bool probe = DO_EXPAND && E.cache != nullptr;
@@ -742,7 +746,7 @@ __device__ __forceinline__ void sim_step_game(const Dev& E, const float* p, cons
                 }
             }
             const unsigned long long hm = __ballot(hit && sub == 0);
-            if (hm && lane == 0) {
+            if (hm && lane == __ffsll((long long)hm) - 1) {        // one of the active lanes
                 unsigned long long* hc = E.cache_hits + wave_id;
                 *hc += (unsigned long long)__popcll(hm);
             }
@@ -761,16 +765,17 @@ __device__ __forceinline__ void sim_step_game(const Dev& E, const float* p, cons
     }
     if (sub == 0) {
         uint4* so = reinterpret_cast<uint4*>(s);
-        if (DO_SELECT) so[1] = make_uint4((uint32_t)nx, (uint32_t)(nx >> 32), (uint32_t)pv, (uint32_t)(pv >> 32));
+        if (DO_SELECT && sel) so[1] = make_uint4((uint32_t)nx, (uint32_t)(nx >> 32), (uint32_t)pv, (uint32_t)(pv >> 32));
         so[2] = make_uint4(root, alloc, h2.z, root_ns);
-        so[3] = make_uint4((uint32_t)kind, DO_SELECT ? (uint32_t)depth : h3.y, err, h3.w + sims);
+        so[3] = make_uint4((uint32_t)kind, (DO_SELECT && sel) ? (uint32_t)depth : h3.y, err, h3.w + sims);
         const uint64_t st_sims = ((uint64_t)c0.x | ((uint64_t)c0.y << 32)) + sims;
         const uint64_t st_steps = ((uint64_t)c0.z | ((uint64_t)c0.w << 32)) + steps;
         const uint64_t st_evals = ((uint64_t)c1.x | ((uint64_t)c1.y << 32)) + evals;
         so[4] = make_uint4((uint32_t)st_sims, (uint32_t)(st_sims >> 32), (uint32_t)st_steps, (uint32_t)(st_steps >> 32));
         so[5] = make_uint4((uint32_t)st_evals, (uint32_t)(st_evals >> 32), c1.z, c1.w);
-        if (DO_SELECT) s->leaf_nm = nm;
+        if (DO_SELECT && sel) s->leaf_nm = nm;
     }
+    return kind;
 }
 
 template <class GM, int GS, bool DO_EXPAND, bool DO_SELECT>
@@ -782,17 +787,121 @@ k_sim_step_p(Dev E, const float* p, const float* v, uint64_t* leaf_bb, int32_t* 
 }
 
 // ---------------------------------------------------------------------------
-// A whole move's simulations in ONE launch, Connect Four with the fused <= 32-channel network: a
-// workgroup owns `gpw` games from the first select to the last backup.  Per simulation its lanes run
-// the search step for their games (sim_step_game, 8 lanes per tree, path kept in the slot), a
-// workgroup barrier, the network for exactly those games' leaves (net_rounds: the task list is dealt
-// to the workgroup's four SIMD pairs as in k_c4net_bf16), another barrier.  A leaf is evaluated by
-// the workgroup that owns its game, so there is no grid-wide synchronisation, no kernel boundary
-// between search and network, and the tower weights are fetched once per move instead of once per
-// simulation.  Workgroups drift apart freely: what one waits for is only its own games.  The
-// network's outputs do not depend on which other leaves share a launch, so trees, visit counts and
-// records are bit-identical to the two-kernel path.
+// Which games each workgroup of the one-launch-per-move kernel serves.  A launch lasts as long as its slowest
+// workgroup, and a game's cost per simulation (how many of its leaves need the network) changes slowly from one
+// move to the next, so the games are dealt by their evaluation count of the previous such launch: sorted by it,
+// then row by row across the workgroups, every other row backwards.  Games that have just started count as the
+// most expensive.  One workgroup; a counting sort on keys 0..1023.  order[w * gpw + i] = i-th game of workgroup w,
+// -1 behind the last one.  Which workgroup serves a game has no influence on its tree.
 // ---------------------------------------------------------------------------
+#define BALANCE_KEYS 1024
+#define BALANCE_MAX_GAMES 16384
+__global__ void __launch_bounds__(1024) k_fused_balance(Dev E, int gpw, int grid) {
+    __shared__ int start[BALANCE_KEYS];
+    __shared__ int scan[BALANCE_KEYS];
+    __shared__ uint16_t keys[BALANCE_MAX_GAMES];
+    const int tid = threadIdx.x;
+    int32_t* order = E.order;
+    uint32_t* last = reinterpret_cast<uint32_t*>(E.order + E.G + 64);
+    start[tid] = 0;
+    for (int i = tid; i < grid * gpw; i += 1024) order[i] = -1;
+    __syncthreads();
+    for (int g = tid; g < E.G; g += 1024) {
+        const Slot* s = E.slots + g;
+        const uint32_t ev = (uint32_t)s->st_evals;
+        uint32_t key = ev - last[g];
+        if (key > BALANCE_KEYS - 1 || s->nm == 0) key = BALANCE_KEYS - 1;
+        last[g] = ev;
+        keys[g] = (uint16_t)key;
+        atomicAdd(&start[BALANCE_KEYS - 1 - key], 1);             // bins in descending key order
+    }
+    __syncthreads();
+    // exclusive prefix sum of the bins
+    const int mine = start[tid];
+    scan[tid] = mine;
+    __syncthreads();
+    for (int d = 1; d < BALANCE_KEYS; d <<= 1) {
+        const int add = tid >= d ? scan[tid - d] : 0;
+        __syncthreads();
+        scan[tid] += add;
+        __syncthreads();
+    }
+    start[tid] = scan[tid] - mine;
+    __syncthreads();
+    for (int g = tid; g < E.G; g += 1024) {
+        const int r = atomicAdd(&start[BALANCE_KEYS - 1 - keys[g]], 1);
+        const int row = r / grid;
+        int w = r - row * grid;
+        if (row & 1) w = grid - 1 - w;
+        order[w * gpw + row] = g;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// A whole move's simulations in ONE launch, Connect Four with the fused <= 32-channel network: a
+// workgroup owns `gpw` games from the first select to the last backup.  A leaf is evaluated by the
+// workgroup that owns its game, so there is no grid-wide synchronisation, no kernel boundary between
+// search and network, and the network weights are fetched (into LDS) once per move instead of once per
+// simulation.
+//
+// Inside the workgroup nothing runs in lock step either.  Every game goes round its own cycle
+//     ready queue --a wave's search step: (expand/backup of the last evaluation,) select-->
+//         leaf queue    (the leaf needs the network)
+//         ready queue   (terminal leaf, backed up at once; or the evaluation was found in the cache)
+//     leaf queue --a wave's network task: tower + heads of two queued leaves (one if no other is in sight)-->
+//         ready queue
+// until the expand/backup that follows its num_sims-th select.  The eight waves are identical workers:
+// a worker takes a network task when two leaves are queued, otherwise up to eight ready games for one
+// search step (eight lanes per tree), otherwise it sleeps.  So the tree walks' memory latency hides behind
+// other games' matrix work, each SIMD has a second wave's MFMA stream to fill the gaps of the first
+// most of the time, and no wave ever waits for a whole round of leaves to be complete: there is no
+// workgroup barrier after the set-up.  A game's own sequence select -> evaluate -> expand/backup is what it
+// is in the lock-step kernels and the network's outputs do not depend on which leaf shares a task, so
+// trees, visit counts and records are bit-identical to the two-kernel path.
+// Hand-offs: (p, v), slots, nodes and leaf positions are written, then a workgroup-scope release fence, then
+// the queue entry (LDS atomics); the taker reads the entry, then an acquire fence.  A queue is a ring of
+// FUSED_QUEUE words (game + 1, 0 = its writer has the slot but has not stored yet) with a head and a tail
+// counter; a game has at most one entry in both queues together, so the rings never wrap onto live entries.
+// A worker that finds nothing to do for WATCHDOG_SPINS polls in a row gives up (a fault elsewhere must not
+// hang the GPU): it sets the abort word, every wave leaves, and bit 4 of the engine's error flags reports it.
+// ---------------------------------------------------------------------------
+#define FUSED_QUEUE 64                 // ring slots >= games per workgroup
+#define WATCHDOG_SPINS (1 << 20)       // x >= 128 cycles per poll: far beyond any wait of a healthy launch
+enum { FC_LEAF_HEAD = 0, FC_LEAF_TAIL, FC_DONE, FC_ABORT, FC_READY_HEAD, FC_READY_TAIL, FC_SEARCHING, FC_GAMES };
+
+__device__ __forceinline__ int lds_load(const int* a) {
+    return __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_store(int* a, int x) {
+    __hip_atomic_store(a, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ int lds_add(int* a, int x) {
+    return __hip_atomic_fetch_add(a, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// one lane appends game gl to a ring (the caller has fenced its writes)
+__device__ __forceinline__ void ring_push(int* ring, int* tail, int gl) {
+    const int t = lds_add(tail, 1);
+    lds_store(ring + (t & (FUSED_QUEUE - 1)), gl + 1);
+}
+// entry `at` of a ring whose head the caller has already moved past it; all lanes call it together
+__device__ __forceinline__ int ring_take(int* ring, int at, int lane) {
+    int* slot = ring + (at & (FUSED_QUEUE - 1));
+    int x;
+    while ((x = uni(lds_load(slot))) == 0) __builtin_amdgcn_s_sleep(1);      // its writer is one store behind
+    if (lane == 0) lds_store(slot, 0);
+    return x - 1;
+}
+// move a ring's head from h to h + n if nobody else has moved it; all lanes call it together
+__device__ __forceinline__ bool ring_claim(int* head, int h, int n, int lane) {
+    int won = 0;
+    if (lane == 0) {
+        int expect = h;
+        won = __hip_atomic_compare_exchange_strong(head, &expect, h + n, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WORKGROUP) ? 1 : 0;
+    }
+    return uni(won) != 0;
+}
+
 __global__ void __launch_bounds__(NTHREADS, 2)
 k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, int32_t* leaf_info, float* p,
                 float* v, int num_sims, int gpw) {
@@ -813,87 +922,141 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
         reinterpret_cast<float*>(scr + S_W2)[tid] = reinterpret_cast<const float*>(blob + OFF_W2)[tid];
     }
     if (tid < 64) reinterpret_cast<float*>(scr + S_BP)[tid] = reinterpret_cast<const float*>(blob + OFF_BP)[tid];
-    load_weights(blob, wlds, tid);         // once per move; ordered before their first use by the barriers below
+    load_weights(blob, wlds, tid);         // once per move
 
-    // search lanes: thread t serves game g_base + t / 8 (gpw <= 64 games per workgroup).  Everything a
-    // search phase needs is re-derived from an opaque copy of the thread index at its start, so no
-    // pointer or index of the search has to stay in a register (or be spilled) across the network phase,
-    // which owns the register file.
+    // LDS words of the hand-offs (all zero now): the task-list area holds the games' select counts, the value
+    // partial-sum area the two rings
+    int* nsel = reinterpret_cast<int*>(scr + S_TL);                      // [64] selects done
+    int* gmap = nsel + 64;                                               // [64] the workgroup's games (E.order)
+    int* leafq = reinterpret_cast<int*>(scr + S_LG + 32 * 64 * 4);       // [FUSED_QUEUE]
+    int* readyq = leafq + FUSED_QUEUE;                                   // [FUSED_QUEUE]
+    int* ctr = reinterpret_cast<int*>(scr + S_WT);                       // FC_* words
+    static_assert(8 * MAXIT * 2 >= 128 && 2 * FUSED_QUEUE * 4 <= 8 * 32 * 4, "LDS areas reused by the hand-off words");
+    uint64_t* lbb = reinterpret_cast<uint64_t*>(scr + S_LBB);            // [64][2] leaf positions
     const int wave_id = (int)blockIdx.x * (NTHREADS / 64) + wave;
-    int* tlist = reinterpret_cast<int*>(scr + S_TL);
-    int* wtot = reinterpret_cast<int*>(scr + S_WT);
-    auto search = [&](auto tag_expand, auto tag_select) {
-        int t = threadIdx.x;
-        asm volatile("" : "+v"(t));
-        const int gl = t / GS, sub = t & (GS - 1), ln = t & 63;
-        const int g = (int)blockIdx.x * gpw + gl;
-        if (gl < gpw && g < E.G) {
-            Slot* s = E.slots + g;
-            uint4* pool = E.pool + (size_t)g * E.cap * (GameC4::A + 1);
-            sim_step_game<GameC4, GS, decltype(tag_expand)::value, decltype(tag_select)::value, true>(
-                E, p, v, leaf_bb, leaf_info, g, ln, sub, s, pool, s->path, wave_id,
-                reinterpret_cast<uint64_t*>(scr + S_LBB) + 2 * gl);
+    if (wave == 0) {
+        // the workgroup's games: the leading non-negative entries of its row of E.order; all start ready for
+        // their first select
+        const int g = lane < gpw ? E.order[(size_t)blockIdx.x * gpw + lane] : -1;
+        gmap[lane] = g;
+        if (g >= 0) readyq[lane] = lane + 1;
+        const int n = __popcll(__ballot(g >= 0));
+        if (lane == 0) { ctr[FC_READY_TAIL] = n; ctr[FC_GAMES] = n; }
+    }
+    __syncthreads();                       // the only time the waves meet
+    const int n_valid = ctr[FC_GAMES];
+
+    const float* sbias = reinterpret_cast<const float*>(scr + S_BIAS);
+    uint8_t* pw = scr + S_PW + wave * PW_BYTES;
+    __bf16* hp = reinterpret_cast<__bf16*>(pw + PW_HP);
+    __bf16* hv = reinterpret_cast<__bf16*>(pw + PW_HV);
+    const int sub = lane & (GS - 1);
+
+    // one search step of game gl by this lane's group of eight
+    auto step = [&](int gl, auto tag_expand, bool sel) {
+        const int g = gmap[gl];
+        Slot* s = E.slots + g;
+        uint4* pool = E.pool + (size_t)g * E.cap * (GameC4::A + 1);
+        const int kind = sim_step_game<GameC4, GS, decltype(tag_expand)::value, true, true>(
+            E, p, v, leaf_bb, leaf_info, g, lane, sub, s, pool, s->path, wave_id, lbb + 2 * gl, sel);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (sub == 0) {
+            if (!sel || num_sims <= 0) {                       // (no simulations asked for: the first select is all)
+                lds_add(ctr + FC_DONE, 1);
+            } else {
+                nsel[gl] += 1;
+                if (kind == AZ_LEAF_EVAL || kind == AZ_LEAF_ROOT) ring_push(leafq, ctr + FC_LEAF_TAIL, gl);
+                else ring_push(readyq, ctr + FC_READY_TAIL, gl);     // terminal (backed up already) or cached
+            }
         }
     };
-    using T_ = std::true_type;
-    using F_ = std::false_type;
 
-#ifdef AZ_EXP_TIMING     // tuning aid (tools/exp_fused_timing.py): shader cycles per phase, summed over workgroups
-    long long t_tree = 0, t_list = 0, t_net = 0, t0 = clock64(), t1;
+#ifdef AZ_EXP_TIMING     // tuning aid (tools/exp_fused_timing.py): what the waves spend their cycles on
+    long long t_task = 0, t_search = 0, t_idle = 0, t0 = clock64(), t1;
+    unsigned long long n_pair = 0, n_single = 0, n_step = 0, n_stepped = 0;
 #define TICK(acc) do { t1 = clock64(); acc += t1 - t0; t0 = t1; } while (0)
 #else
 #define TICK(acc) do { } while (0)
 #endif
-    search(F_{}, T_{});
-    for (int sim = 0; sim < num_sims; ++sim) {
-        // the task list starts every simulation empty
-        if (tid < 8 * MAXIT * 2) tlist[tid] = 0;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");        // leaves written by the search lanes
-        __syncthreads();
-        TICK(t_tree);
-        if (wave == 0) {
-            // rank the games that need the network and deal them to the four SIMD pairs
-            const int gg = (int)blockIdx.x * gpw + lane;
-            bool need = false;
-            if (lane < gpw && gg < E.G) {
-                const int kind = leaf_info[gg] & 0xFF;
-                need = kind == AZ_LEAF_EVAL || kind == AZ_LEAF_ROOT;
+    for (int spins = 0;;) {
+        if (uni(lds_load(ctr + FC_ABORT)) || uni(lds_load(ctr + FC_DONE)) >= n_valid) break;
+        const int lh = uni(lds_load(ctr + FC_LEAF_HEAD)), leaves = uni(lds_load(ctr + FC_LEAF_TAIL)) - lh;
+        const int rh = uni(lds_load(ctr + FC_READY_HEAD)), ready = uni(lds_load(ctr + FC_READY_TAIL)) - rh;
+        // a lone leaf is taken only when no second one can turn up soon: nothing ready, nothing being searched
+        if (leaves >= 2 || (leaves == 1 && ready <= 0 && uni(lds_load(ctr + FC_SEARCHING)) == 0)) {
+            const int take = leaves >= 2 ? 2 : 1;
+            if (!ring_claim(ctr + FC_LEAF_HEAD, lh, take, lane)) continue;
+            TICK(t_idle);
+            const int g0 = ring_take(leafq, lh, lane), g1 = take == 2 ? ring_take(leafq, lh + 1, lane) : -1;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (g1 >= 0) {
+                const int g_mine = (lane & 8) ? g1 : g0;
+                trunk_task<ROWS>(wlds, sbias, num_blocks, lbb + 2 * g_mine, hp, hv, 0, lane);
+            } else {
+                trunk_task<ROWS / 2>(wlds, sbias, num_blocks, lbb + 2 * g0, hp, hv, 0, lane);
             }
-            const unsigned long long mask = __ballot(need);
-            const int total = __popcll(mask), rank = __popcll(mask & ((1ull << lane) - 1ull));
-            const int base = total >> 2, rem = total & 3;
-            if (need) {
-                const int big = rem * (base + 1);
-                int unit, pos;
-                if (rank < big) { unit = rank / (base + 1); pos = rank - unit * (base + 1); }
-                else { const int q = (rank - big) / base; unit = rem + q; pos = rank - big - q * base; }
-                const int len = base + (unit < rem), na = len - 2 * ((len + 1) >> 2);
-                const int w = unit + (pos < na ? 0 : 4), q = pos < na ? pos : pos - na;
-                tlist[w * MAXIT * 2 + q] = gg + 1;
-            }
+            heads_wave(wlds, scr, wave, lane, gmap[g0], g1 >= 0 ? gmap[g1] : -1, lbb + 2 * g0,
+                       lbb + 2 * (g1 >= 0 ? g1 : g0), p, v);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) {
-                const int len = base + (0 < rem), na = len - 2 * ((len + 1) >> 2);
-                wtot[0] = (na + 3) >> 2;
+                ring_push(readyq, ctr + FC_READY_TAIL, g0);
+                if (g1 >= 0) ring_push(readyq, ctr + FC_READY_TAIL, g1);
             }
+            TICK(t_task);
+#ifdef AZ_EXP_TIMING
+            if (g1 >= 0) ++n_pair; else ++n_single;
+#endif
+            spins = 0;
+            continue;
         }
-        __syncthreads();
-        const int nrounds = wtot[0];
-        TICK(t_list);
-        net_rounds<true>(blob, num_blocks, leaf_bb, (int)blockIdx.x * gpw, p, v, wlds, scr, nrounds, tid, wave, lane);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");        // (p, v) written by the head phase
-        __syncthreads();
-        TICK(t_net);
-        if (sim + 1 < num_sims) search(T_{}, T_{});
-        else search(T_{}, F_{});
+        if (ready > 0) {
+            const int take = ready < 8 ? ready : 8;
+            if (!ring_claim(ctr + FC_READY_HEAD, rh, take, lane)) continue;
+            TICK(t_idle);
+            if (lane == 0) lds_add(ctr + FC_SEARCHING, take);
+            __builtin_amdgcn_s_setprio(3);     // few instructions, all on the critical path of some network task
+            int gl = -1;
+            for (int i = 0; i < take; ++i) {
+                const int x = ring_take(readyq, rh + i, lane);
+                if ((lane >> 3) == i) gl = x;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (gl >= 0) {
+                const int done = nsel[gl];
+                if (done == 0) step(gl, std::false_type{}, true);          // the game's first select
+                else step(gl, std::true_type{}, done < num_sims);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            if (lane == 0) lds_add(ctr + FC_SEARCHING, -take);             // after the pushes of this step
+            TICK(t_search);
+#ifdef AZ_EXP_TIMING
+            ++n_step; n_stepped += take;
+#endif
+            spins = 0;
+            continue;
+        }
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > WATCHDOG_SPINS) {
+            if (lane == 0) {
+                lds_store(ctr + FC_ABORT, 1);
+                atomicOr(reinterpret_cast<unsigned int*>(E.ring_count + 1), 16u);
+            }
+            break;
+        }
     }
 #ifdef AZ_EXP_TIMING
-    net_dbg_flush(scr, wave, lane);
-    if (tid == 0) {
+    TICK(t_idle);
+    if (lane == 0) {
         unsigned long long* dbg = reinterpret_cast<unsigned long long*>(E.ring_count + 16);
-        atomicAdd(dbg + 0, (unsigned long long)t_tree);
-        atomicAdd(dbg + 1, (unsigned long long)t_list);
-        atomicAdd(dbg + 2, (unsigned long long)t_net);
+        atomicAdd(dbg + 0, (unsigned long long)t_task);
+        atomicAdd(dbg + 1, (unsigned long long)t_search);
+        atomicAdd(dbg + 2, (unsigned long long)t_idle);
         atomicAdd(dbg + 3, 1ull);
+        atomicAdd(&g_net_dbg[0], n_pair);
+        atomicAdd(&g_net_dbg[1], n_single);
+        atomicAdd(&g_net_dbg[2], n_step);
+        atomicAdd(&g_net_dbg[3], n_stepped);
+        atomicMax(&g_net_dbg[4], (unsigned long long)(t_task + t_search + t_idle));
     }
 #endif
 #undef TICK
@@ -1268,8 +1431,10 @@ static int engine_alloc(az_engine* e) {
         (err = hipMalloc(&d.slots, (size_t)d.G * sizeof(Slot))) != hipSuccess ||
         (err = hipMalloc(&d.rec_visits, (size_t)d.G * AZ_MAX_MOVES * AZ_MAX_ACTIONS * 4)) != hipSuccess ||
         (err = hipMalloc(&d.ring, (size_t)d.ring_cap * sizeof(az_game_record))) != hipSuccess ||
-        (err = hipMalloc(&d.ring_count, 512)) != hipSuccess)
+        (err = hipMalloc(&d.ring_count, 512)) != hipSuccess ||
+        (err = hipMalloc(&d.order, ((size_t)2 * d.G + 64) * 4)) != hipSuccess)
         return az_fail("hipMalloc (node pools)", err);
+    HIPCHK(hipMemset(d.order, 0, ((size_t)2 * d.G + 64) * 4));
     HIPCHK(hipMemset(d.slots, 0, (size_t)d.G * sizeof(Slot)));
     HIPCHK(hipMemset(d.rec_visits, 0, (size_t)d.G * AZ_MAX_MOVES * AZ_MAX_ACTIONS * 4));
     HIPCHK(hipMemset(d.ring_count, 0, 512));
@@ -1327,7 +1492,7 @@ int az_engine_destroy(az_engine* e) {
     if (!e) return 0;
     DeviceScope scope(e->cfg.device);
     (void)hipFree(e->d.pool); (void)hipFree(e->d.slots); (void)hipFree(e->d.rec_visits); (void)hipFree(e->d.ring);
-    (void)hipFree(e->d.ring_count); (void)hipFree(e->lut_dev); (void)hipFree(e->d.cache); (void)hipFree(e->d.cache_hits);
+    (void)hipFree(e->d.ring_count); (void)hipFree(e->d.order); (void)hipFree(e->lut_dev); (void)hipFree(e->d.cache); (void)hipFree(e->d.cache_hits);
     delete e;
     return 0;
 }
@@ -1497,6 +1662,8 @@ static int fused_launch(az_engine* e, const uint8_t* blob, int32_t num_blocks, u
     const int grid = (e->d.G + gpw - 1) / gpw;
     // already done by az_engine_create on this device (a bitmap test, then nothing)
     if (int rc = az_set_kernel_lds(reinterpret_cast<const void*>(k_c4_move_fused), LDS_BYTES, g_fused_attr_done)) return rc;
+    if (e->d.G > BALANCE_MAX_GAMES) return az_fail("az_c4_move_fused: more than 16384 games");
+    hipLaunchKernelGGL(k_fused_balance, dim3(1), dim3(1024), 0, st, e->d, gpw, grid);
     hipLaunchKernelGGL(k_c4_move_fused, dim3(grid), dim3(NTHREADS), LDS_BYTES, st, e->d, blob, (int)num_blocks, leaf_bb,
                        leaf_info, p, v, (int)e->d.S, gpw);
     AZ_LAUNCH_CHECK("k_c4_move_fused");

@@ -338,6 +338,90 @@ __device__ __forceinline__ void trunk_task(const uint8_t* wlds, const float* sbi
     }
 }
 
+// The fully connected heads of the (up to two) boards whose planes this wave has just left in board slots 0, 1 of
+// its own scratch, with no other wave involved: value FC 42->256->1 + tanh and policy FC 84->42 + landing-cell
+// gather + soft-max, the same arithmetic in the same order as the workgroup-wide head phase of net_rounds (whose
+// 32 MFMA columns are four boards of eight waves; here every column repeats slot 0 or 1), so the results are
+// bit-identical.  g0 / g1 = leaf indices (g1 < 0: none), pos0 / pos1 their positions.  The logits pass through the
+// wave's own four rows of scr + S_LG.
+__device__ __forceinline__ void heads_wave(const uint8_t* wlds, uint8_t* scr, int wave, int lane, int g0, int g1,
+                                           const uint64_t* pos0, const uint64_t* pos1, float* p_out, float* v_out) {
+    const float* sbias = reinterpret_cast<const float*>(scr + S_BIAS);
+    const float* sb1 = reinterpret_cast<const float*>(scr + S_B1);
+    const float* sw2 = reinterpret_cast<const float*>(scr + S_W2);
+    const float* sbp = reinterpret_cast<const float*>(scr + S_BP);
+    const uint8_t* pw = scr + S_PW + wave * PW_BYTES;
+    float* lg = reinterpret_cast<float*>(scr + S_LG) + wave * 4 * 64;
+    const int hh = lane >> 5, c = lane & 31;
+    const __bf16* chp = reinterpret_cast<const __bf16*>(pw + PW_HP) + (c & 1) * 96;
+    const __bf16* chv = reinterpret_cast<const __bf16*>(pw + PW_HV) + (c & 1) * 48;
+    float sv = 0.0f;                                           // column c & 1: sum over the eight row tiles, in order
+#pragma unroll 2
+    for (int hw = 0; hw < 8; ++hw) {
+        float part = 0.0f;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const bf16x8 a = frag_ptr(wlds, OFF_F1 + (hw * 3 + s) * 1024, lane)[0];
+            acc = MFMA(a, *reinterpret_cast<const bf16x8*>(chv + 16 * s + 8 * hh), acc);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(sb1 + 32 * hw + 8 * g + 4 * hh);
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(sw2 + 32 * hw + 8 * g + 4 * hh);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) part = fmaf(fmaxf(acc[4 * g + i] + b1[i], 0.0f), wv[i], part);
+        }
+        part += __shfl_xor(part, 32);
+        sv += part;
+    }
+#pragma unroll
+    for (int hn = 0; hn < 2; ++hn) {
+        f32x16 pacc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pacc[i] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            const bf16x8 a = frag_ptr(wlds, OFF_PF + (hn * 6 + s) * 1024, lane)[0];
+            pacc = MFMA(a, *reinterpret_cast<const bf16x8*>(chp + 16 * s + 8 * hh), pacc);
+        }
+        if (c < 2) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bp = *reinterpret_cast<const f32x4*>(sbp + 32 * hn + 8 * g + 4 * hh);
+                f32x4 o4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o4[i] = pacc[4 * g + i] + bp[i];
+                *reinterpret_cast<f32x4*>(lg + c * 64 + 32 * hn + 8 * g + 4 * hh) = o4;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");     // this wave's logits, before its own reads below
+    if (lane < 16) {
+        // landing-cell gather (connectfour.py:56-71) + soft-max over legal columns (mcts.py:106)
+        const int b = lane >> 3, col = lane & 7;
+        const int gidx = b ? g1 : g0;
+        const uint64_t* pos = b ? pos1 : pos0;
+        uint64_t occ = 0;
+        if (gidx >= 0) occ = pos[0] | pos[1];
+        const int height = col < 7 ? __popcll((occ >> (7 * col)) & 0x3Full) : 6;
+        const bool legal = col < 7 && height < 6;
+        const float logit = legal ? lg[b * 64 + height * 7 + col] : -INFINITY;
+        float m = logit;
+        m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4));
+        const float e = legal ? __expf(logit - m) : 0.0f;
+        float sum = e;
+        sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
+        if (col < 7 && gidx >= 0) p_out[(size_t)gidx * 7 + col] = legal ? e / sum : 0.0f;
+    }
+    if (lane < 2) {
+        const int gidx = lane ? g1 : g0;
+        if (gidx >= 0) v_out[gidx] = tanhf(sv + sbias[99]);
+    }
+}
+
 #ifdef AZ_EXP_TIMING     // tuning aid: shader cycles per part of the network phase, summed over waves
 // 0 stem+first centre, 1 tower, 2 head convs, 3 wait for the other waves, 4 fully connected heads + soft-max,
 // 5 tasks, 6 waves that had a task, 7 waves without one: their whole wait

@@ -2,8 +2,8 @@
 """Phase split of the one-launch-per-move kernel (tuning aid).  Needs a library built with the cycle
 counters compiled in:
     make -C alphazero_amd/csrc HIPFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -DAZ_EXP_TIMING"
-and prints, per move, the shader cycles a workgroup spends per simulation in the search phase, in
-ranking its leaves and in the network phase.  Rebuild without the flag afterwards."""
+and prints, per move, how the waves' cycles divide into network tasks, search steps and idling, and how many
+tasks had two leaves.  Rebuild without the flag afterwards."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -22,13 +22,15 @@ out = (C.c_ulonglong * 12)()
 for i in range(12):
     bb, info = eng.begin_move(); p, _ = net(bb, info); eng.apply_root(p)
     eng.lib.az_debug_counters(eng.h, out)
-    eng.move_fused(net)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(); eng.move_fused(net); ev1.record(); torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1)
     eng.choose_and_advance(); eng.drain_finished()
     eng.lib.az_debug_counters(eng.h, out)
     n = out[3]
-    print(f'move {i}: per WG per sim, shader cycles: tree {out[0]/n/S:.0f}  list {out[1]/n/S:.0f}  net {out[2]/n/S:.0f}  (WGs {n})')
     d = out[4:12]
-    tasks, busy, idle = max(d[5], 1), max(d[6], 1), max(d[7], 1)
-    print(f'   network phase, per wave with work: stem {d[0]/tasks:.0f}/task  tower {d[1]/tasks:.0f}/task  head convs {d[2]/busy:.0f}  '
-          f'wait {d[3]/busy:.0f}  fc+softmax {d[4]/(busy+idle):.0f};  tasks per WG-sim {tasks/n/S:.2f}, waves with work {busy/n/S:.2f}, '
-          f'idle waves wait {d[7]/idle:.0f}')
+    tot = (out[0] + out[1] + out[2]) / n
+    print(f'move {i}: launch {ms:.2f} ms; per wave: total {tot:.0f} cycles ({tot / (ms * 1e3):.0f} MHz), slowest {d[4]}; '
+          f'task {out[0] / n / tot:.1%} search {out[1] / n / tot:.1%} idle {out[2] / n / tot:.1%}')
+    print(f'   tasks: {d[0]} pairs ({out[0] / max(d[0] + d[1], 1):.0f} cycles per task incl. singles), {d[1]} singles; '
+          f'search steps {d[2]} with {d[3] / max(d[2], 1):.2f} games each, {out[1] / max(d[2], 1):.0f} cycles per step')
