@@ -972,7 +972,7 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
     };
 
 #ifdef AZ_EXP_TIMING     // tuning aid (tools/exp_fused_timing.py): what the waves spend their cycles on
-    long long t_task = 0, t_search = 0, t_idle = 0, t0 = clock64(), t1;
+    long long t_task = 0, t_search = 0, t_idle = 0, t_heads = 0, t_fence = 0, t0 = clock64(), t1;
     unsigned long long n_pair = 0, n_single = 0, n_step = 0, n_stepped = 0;
 #define TICK(acc) do { t1 = clock64(); acc += t1 - t0; t0 = t1; } while (0)
 #else
@@ -995,14 +995,18 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
             } else {
                 trunk_task<ROWS / 2>(wlds, sbias, num_blocks, lbb + 2 * g0, hp, hv, 0, lane);
             }
+#ifdef AZ_EXP_TIMING
+            TICK(t_task);
+#endif
             heads_wave(wlds, scr, wave, lane, gmap[g0], g1 >= 0 ? gmap[g1] : -1, lbb + 2 * g0,
                        lbb + 2 * (g1 >= 0 ? g1 : g0), p, v);
+            TICK(t_heads);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) {
                 ring_push(readyq, ctr + FC_READY_TAIL, g0);
                 if (g1 >= 0) ring_push(readyq, ctr + FC_READY_TAIL, g1);
             }
-            TICK(t_task);
+            TICK(t_fence);
 #ifdef AZ_EXP_TIMING
             if (g1 >= 0) ++n_pair; else ++n_single;
 #endif
@@ -1056,7 +1060,9 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
         atomicAdd(&g_net_dbg[1], n_single);
         atomicAdd(&g_net_dbg[2], n_step);
         atomicAdd(&g_net_dbg[3], n_stepped);
-        atomicMax(&g_net_dbg[4], (unsigned long long)(t_task + t_search + t_idle));
+        atomicMax(&g_net_dbg[4], (unsigned long long)(t_task + t_heads + t_fence + t_search + t_idle));
+        atomicAdd(&g_net_dbg[6], (unsigned long long)t_fence);
+        atomicAdd(&g_net_dbg[5], (unsigned long long)t_heads);
     }
 #endif
 #undef TICK

@@ -355,49 +355,91 @@ __device__ __forceinline__ void heads_wave(const uint8_t* wlds, uint8_t* scr, in
     const int hh = lane >> 5, c = lane & 31;
     const __bf16* chp = reinterpret_cast<const __bf16*>(pw + PW_HP) + (c & 1) * 96;
     const __bf16* chv = reinterpret_cast<const __bf16*>(pw + PW_HV) + (c & 1) * 48;
+    // One wave alone has nobody to hide its LDS latency behind, so every group of operands is requested in one
+    // batch, a scheduling fence keeps the batch together, and the arithmetic follows.
+#define HEADS_FENCE() __builtin_amdgcn_sched_barrier(0)
     float sv = 0.0f;                                           // column c & 1: sum over the eight row tiles, in order
-#pragma unroll 2
-    for (int hw = 0; hw < 8; ++hw) {
-        float part = 0.0f;
-        f32x16 acc;
+    bf16x8 bv[3];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int s = 0; s < 3; ++s) bv[s] = *reinterpret_cast<const bf16x8*>(chv + 16 * s + 8 * hh);
+    // four row tiles at a time: their MFMA chains are independent and hide each other's latency
+#pragma unroll 1
+    for (int h4 = 0; h4 < 8; h4 += 4) {
+        bf16x8 wf[4][3];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const bf16x8 a = frag_ptr(wlds, OFF_F1 + (hw * 3 + s) * 1024, lane)[0];
-            acc = MFMA(a, *reinterpret_cast<const bf16x8*>(chv + 16 * s + 8 * hh), acc);
-        }
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(sb1 + 32 * hw + 8 * g + 4 * hh);
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(sw2 + 32 * hw + 8 * g + 4 * hh);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) part = fmaf(fmaxf(acc[4 * g + i] + b1[i], 0.0f), wv[i], part);
-        }
-        part += __shfl_xor(part, 32);
-        sv += part;
-    }
-#pragma unroll
-    for (int hn = 0; hn < 2; ++hn) {
-        f32x16 pacc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) pacc[i] = 0.0f;
-#pragma unroll
-        for (int s = 0; s < 6; ++s) {
-            const bf16x8 a = frag_ptr(wlds, OFF_PF + (hn * 6 + s) * 1024, lane)[0];
-            pacc = MFMA(a, *reinterpret_cast<const bf16x8*>(chp + 16 * s + 8 * hh), pacc);
-        }
-        if (c < 2) {
+            for (int s = 0; s < 3; ++s) wf[t][s] = frag_ptr(wlds, OFF_F1 + ((h4 + t) * 3 + s) * 1024, lane)[0];
+        f32x4 b1v[2][4], w2v[2][4];                            // biases / second-layer weights of tile t (slot t & 1)
+        auto load_bw = [&](int t) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 bp = *reinterpret_cast<const f32x4*>(sbp + 32 * hn + 8 * g + 4 * hh);
-                f32x4 o4;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o4[i] = pacc[4 * g + i] + bp[i];
-                *reinterpret_cast<f32x4*>(lg + c * 64 + 32 * hn + 8 * g + 4 * hh) = o4;
+                b1v[t & 1][g] = *reinterpret_cast<const f32x4*>(sb1 + 32 * (h4 + t) + 8 * g + 4 * hh);
+                w2v[t & 1][g] = *reinterpret_cast<const f32x4*>(sw2 + 32 * (h4 + t) + 8 * g + 4 * hh);
             }
+        };
+        load_bw(0);
+        HEADS_FENCE();
+        f32x16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = MFMA(wf[t][s], bv[s], acc[t]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t + 1 < 4) load_bw(t + 1);
+            HEADS_FENCE();
+            float part = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b1 = b1v[t & 1][g], wv = w2v[t & 1][g];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) part = fmaf(fmaxf(acc[t][4 * g + i] + b1[i], 0.0f), wv[i], part);
+            }
+            part += __shfl_xor(part, 32);
+            sv += part;
         }
     }
+    {
+        bf16x8 pf[2][6], bp8[6];
+        f32x4 bpv[2][4];
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            bp8[s] = *reinterpret_cast<const bf16x8*>(chp + 16 * s + 8 * hh);
+#pragma unroll
+            for (int hn = 0; hn < 2; ++hn) pf[hn][s] = frag_ptr(wlds, OFF_PF + (hn * 6 + s) * 1024, lane)[0];
+        }
+#pragma unroll
+        for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bpv[hn][g] = *reinterpret_cast<const f32x4*>(sbp + 32 * hn + 8 * g + 4 * hh);
+        HEADS_FENCE();
+        f32x16 pacc[2];
+#pragma unroll
+        for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) pacc[hn][i] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 6; ++s)
+#pragma unroll
+            for (int hn = 0; hn < 2; ++hn) pacc[hn] = MFMA(pf[hn][s], bp8[s], pacc[hn]);
+        if (c < 2) {
+#pragma unroll
+            for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 o4;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o4[i] = pacc[hn][4 * g + i] + bpv[hn][g][i];
+                    *reinterpret_cast<f32x4*>(lg + c * 64 + 32 * hn + 8 * g + 4 * hh) = o4;
+                }
+        }
+    }
+#undef HEADS_FENCE
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");     // this wave's logits, before its own reads below
     if (lane < 16) {
         // landing-cell gather (connectfour.py:56-71) + soft-max over legal columns (mcts.py:106)

@@ -29,8 +29,8 @@ for i in range(12):
     eng.lib.az_debug_counters(eng.h, out)
     n = out[3]
     d = out[4:12]
-    tot = (out[0] + out[1] + out[2]) / n
+    tot = (out[0] + out[1] + out[2] + d[5] + d[6]) / n
     print(f'move {i}: launch {ms:.2f} ms; per wave: total {tot:.0f} cycles ({tot / (ms * 1e3):.0f} MHz), slowest {d[4]}; '
-          f'task {out[0] / n / tot:.1%} search {out[1] / n / tot:.1%} idle {out[2] / n / tot:.1%}')
-    print(f'   tasks: {d[0]} pairs ({out[0] / max(d[0] + d[1], 1):.0f} cycles per task incl. singles), {d[1]} singles; '
+          f'towers {out[0] / n / tot:.1%} heads {d[5] / n / tot:.1%} hand-over {d[6] / n / tot:.1%} search {out[1] / n / tot:.1%} idle {out[2] / n / tot:.1%}')
+    print(f'   tasks: {d[0]} pairs ({out[0] / max(d[0] + d[1], 1):.0f} + {d[5] / max(d[0] + d[1], 1):.0f} cycles per task incl. singles), {d[1]} singles; '
           f'search steps {d[2]} with {d[3] / max(d[2], 1):.2f} games each, {out[1] / max(d[2], 1):.0f} cycles per step')
