@@ -1019,11 +1019,14 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
             TICK(t_idle);
             if (lane == 0) lds_add(ctr + FC_SEARCHING, take);
             __builtin_amdgcn_s_setprio(3);     // few instructions, all on the critical path of some network task
-            int gl = -1;
-            for (int i = 0; i < take; ++i) {
-                const int x = ring_take(readyq, rh + i, lane);
-                if ((lane >> 3) == i) gl = x;
+            // lane i < take fetches entry i, then group i of eight lanes takes it over
+            int mine = 0;
+            if (lane < take) {
+                int* slot = readyq + ((rh + lane) & (FUSED_QUEUE - 1));
+                while ((mine = lds_load(slot)) == 0) __builtin_amdgcn_s_sleep(1);      // its writer is one store behind
+                lds_store(slot, 0);
             }
+            const int gl = __shfl(mine, lane >> 3) - 1;                              // -1: no game for this group
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (gl >= 0) {
                 const int done = nsel[gl];
