@@ -539,8 +539,8 @@ def main():
                                'traffic': pmc_traffic('k_c4_move_fused'), 'avg_launch_ms': ms,
                                'flops_per_leaf': trunk_flops_per_leaf(blocks, ch),
                                'leaves_per_launch': (evals - hits) / args.steps,
-                               'note': 'search and network phases of all simulations of a move; the search phases '
-                                       'do no matrix work'}
+                               'note': 'all simulations of a move: tree walks and network tasks of different games '
+                                       'interleaved on the same waves; the tree walks do no matrix work'}
         if net is not None and args.net_impl == 'hip' and net_ev and tree_ev:
             ms = avg_ms(net_ev)
             # leaves one launch evaluates x flops per leaf; the 128-channel kernels take every leaf of
