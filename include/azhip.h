@@ -168,8 +168,10 @@ int  az_take_finished_device(az_engine* e, az_game_record* out_dev, int32_t max_
 int  az_get_stats(az_engine* e, az_stats* out_host, void* stream);
 /* Error bits of any game, as seen by the az_drain_finished calls since the last az_reset_games: bit 0 = a
  * game's node pool ran out (its later simulations are lost), bit 1 = the record ring overflowed (finished
- * games were dropped: drain more often).  Host-side read, no device work; -1 for a null engine.  The
- * reference cannot fail this way (it allocates per node and per game).                                */
+ * games were dropped: drain more often), bit 4 = a wave of az_c4_move_fused found nothing to do for far
+ * longer than any healthy launch lets it wait and the launch was abandoned (a fault in the library or
+ * the device; that move's searches are incomplete).  Host-side read, no device work; -1 for a null
+ * engine.  The reference cannot fail this way (it allocates per node and per game).                    */
 int  az_engine_error_flags(const az_engine* e);
 
 /* Training examples of finished games, built on the device: what ReplayBufferDataset.__getitem__
@@ -267,12 +269,13 @@ int  az_c4net128_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uin
 
 /* All S simulations of a move in ONE launch, Connect Four with the <= 32-channel network: replaces
  * the S x { network, az_sim_step } loop above (selfplay.py:24-38 / mcts.py:119-158 between
- * az_apply_root and az_choose_and_advance).  A workgroup owns its games for the whole move: search
- * step, network for those games' leaves, search step, ... with workgroup barriers only.  blob as for
- * az_c4net_bf16_forward; leaf_bb / leaf_info / p / v are the engine-sized DEVICE buffers of the
- * stepwise calls (used as scratch between the phases).  Up to az_c4_move_fused_max_games() games per engine (16384 on an
- * MI355X); the evaluation
- * cache is used when enabled.  Results are bit-identical to the stepwise loop with az_c4net_bf16_forward. */
+ * az_apply_root and az_choose_and_advance).  A workgroup owns its games for the whole move, and
+ * every game goes through select, network, expand / backup at its own pace (the games of a workgroup
+ * are not in lock step; which games share a workgroup is decided per call from their cost in the
+ * previous call).  blob as for az_c4net_bf16_forward; leaf_bb / leaf_info / p / v are the engine-sized
+ * DEVICE buffers of the stepwise calls (used as scratch between search steps and network tasks).  Up
+ * to az_c4_move_fused_max_games() games per engine (16384 on an MI355X); the evaluation cache is used
+ * when enabled.  Results are bit-identical to the stepwise loop with az_c4net_bf16_forward.          */
 int  az_c4_move_fused(az_engine* e, const uint8_t* blob, int32_t num_blocks, uint64_t* leaf_bb,
                       int32_t* leaf_info, float* p, float* v, void* stream);
 /* largest engine (games) az_c4_move_fused accepts on the engine's device: 64 games per compute unit */
@@ -281,10 +284,10 @@ int  az_c4_move_fused_max_games(const az_engine* e);
 /* az_c4_move_fused without its four staging arguments and without any allocation.  No counterpart in the
  * reference; for callers that cannot allocate device memory or pass a workspace: code under HIP graph capture,
  * tight serving loops, harnesses that forbid hipMalloc.  The staging arrays (leaf positions, leaf words, priors,
- * values that travel between the search and network phases) live in a fixed area of device memory that is part
+ * values that travel between search steps and network tasks) live in a fixed area of device memory that is part
  * of the library image, 832 KiB per GPU, sized for engines of up to 16384 games: a larger engine is refused
- * with an error.  The call issues one kernel launch on `stream` and nothing else (no hipMalloc / hipFree, no
- * memset: every staging word is written by the kernel before it is read, so stale contents of the previous
+ * with an error.  The call issues its two kernel launches on `stream` and nothing else (no hipMalloc / hipFree,
+ * no memset: every staging word is written by the kernel before it is read, so stale contents of the previous
  * call are harmless).  All engines on one GPU share that GPU's area: two calls that overlap in time on one GPU
  * race; calls ordered on one stream, or on different GPUs, do not.  Trees, visit counts and records are
  * bit-identical to az_c4_move_fused.                                                                     */
