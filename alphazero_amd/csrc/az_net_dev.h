@@ -194,51 +194,56 @@ __device__ __forceinline__ void tap_rows(f32x4 (&acc)[NT][2], const bf16x8 (&s)[
     }
 }
 
-// The eight taps around the centre of conv CONV over `in`, plus (RES) the identity tap over `res`.  On entry
-// w = weights of tap (0,1) of CONV, on exit w = weights of the centre tap of conv NEXT.
+// The eight taps around the centre of conv CONV over `in`, plus (RES) the identity tap over `res`.  Weights are
+// requested TWO taps ahead of their MFMAs (one region of ten or twelve MFMAs does not cover the LDS latency when
+// eight waves are reading): on entry w = weights of tap (0,1) of CONV and nx = those of tap (2,1), already
+// requested; on exit w = weights of the centre tap of conv NEXT and nx = those of its tap (0,1).
 template <int CONV, int NEXT, bool RES, int NT>
 __device__ __forceinline__ void conv_rest(const uint8_t* wlds, const bf16x8 (&in)[NT], const bf16x8 (&res)[NT],
-                                          f32x4 (&acc)[NT][2], WPair& w, int lane) {
+                                          f32x4 (&acc)[NT][2], WPair& w, WPair& nx, int lane) {
     WPair n;
     bf16x8 sl[NT], sr[NT];
     constexpr int H = NT / 2 + (NT & 1), T3 = NT / 3;
+#define NEXT_TAP() do { w = nx; nx = n; FENCE(); } while (0)
     // centre column of the window; meanwhile the rows as seen from the right-hand neighbour (window column 0)
-    n = wload<CONV, 2, 1>(wlds, lane); tap_rows<0, NT>(acc, in, w);
+    n = RES ? wload<2, 0, 0>(wlds, lane) : wload<CONV, 1, 0>(wlds, lane); tap_rows<0, NT>(acc, in, w);
 #pragma unroll
     for (int y = 0; y < H; ++y) sl[y] = shift_cell<true>(in[y]);
-    w = n; FENCE();
-    n = RES ? wload<2, 0, 0>(wlds, lane) : wload<CONV, 1, 0>(wlds, lane); tap_rows<2, NT>(acc, in, w);
+    NEXT_TAP();
+    n = RES ? wload<CONV, 1, 0>(wlds, lane) : wload<CONV, 0, 0>(wlds, lane); tap_rows<2, NT>(acc, in, w);
 #pragma unroll
     for (int y = H; y < NT; ++y) sl[y] = shift_cell<true>(in[y]);
-    w = n; FENCE();
+    NEXT_TAP();
     if (RES) {
-        n = wload<CONV, 1, 0>(wlds, lane); tap_rows<1, NT>(acc, res, w); w = n; FENCE();
+        n = wload<CONV, 0, 0>(wlds, lane); tap_rows<1, NT>(acc, res, w); NEXT_TAP();
     }
     // window column 0; meanwhile the rows as seen from the left-hand neighbour (window column 2)
-    n = wload<CONV, 0, 0>(wlds, lane); tap_rows<1, NT>(acc, sl, w);
+    n = wload<CONV, 2, 0>(wlds, lane); tap_rows<1, NT>(acc, sl, w);
 #pragma unroll
     for (int y = 0; y < T3; ++y) sr[y] = shift_cell<false>(in[y]);
-    w = n; FENCE();
-    n = wload<CONV, 2, 0>(wlds, lane); tap_rows<0, NT>(acc, sl, w);
+    NEXT_TAP();
+    n = wload<CONV, 1, 2>(wlds, lane); tap_rows<0, NT>(acc, sl, w);
 #pragma unroll
     for (int y = T3; y < 2 * T3; ++y) sr[y] = shift_cell<false>(in[y]);
-    w = n; FENCE();
-    n = wload<CONV, 1, 2>(wlds, lane); tap_rows<2, NT>(acc, sl, w);
+    NEXT_TAP();
+    n = wload<CONV, 0, 2>(wlds, lane); tap_rows<2, NT>(acc, sl, w);
 #pragma unroll
     for (int y = 2 * T3; y < NT; ++y) sr[y] = shift_cell<false>(in[y]);
-    w = n; FENCE();
+    NEXT_TAP();
     // window column 2
-    n = wload<CONV, 0, 2>(wlds, lane); tap_rows<1, NT>(acc, sr, w); w = n; FENCE();
-    n = wload<CONV, 2, 2>(wlds, lane); tap_rows<0, NT>(acc, sr, w); w = n; FENCE();
-    n = wload<NEXT, 1, 1>(wlds, lane); tap_rows<2, NT>(acc, sr, w); w = n; FENCE();
+    n = wload<CONV, 2, 2>(wlds, lane); tap_rows<1, NT>(acc, sr, w); NEXT_TAP();
+    n = wload<NEXT, 1, 1>(wlds, lane); tap_rows<0, NT>(acc, sr, w); NEXT_TAP();
+    n = wload<NEXT, 0, 1>(wlds, lane); tap_rows<2, NT>(acc, sr, w); NEXT_TAP();
+#undef NEXT_TAP
 }
 
 // Between two convs: acc -> out (ReLU, bf16) and, when CENTRE, the centre tap of the next conv with its bias as
-// the C operand.  On entry w = centre weights of conv NEXT, on exit w = weights of its tap (0,1).
+// the C operand.  On entry w = centre weights of conv NEXT and nx = weights of its tap (0,1), already requested;
+// on exit w = weights of tap (0,1) and nx = those of tap (2,1).
 template <int NEXT, bool CENTRE, int NT>
 __device__ __forceinline__ void between_convs(const uint8_t* wlds, f32x4 (&acc)[NT][2], bf16x8 (&out)[NT],
-                                              const Bias2& bias, WPair& w, int lane) {
-    const WPair n = wload<NEXT, 0, 1>(wlds, lane);
+                                              const Bias2& bias, WPair& w, WPair& nx, int lane) {
+    const WPair n = wload<NEXT, 2, 1>(wlds, lane);
 #pragma unroll
     for (int y = 0; y < NT; ++y) {
         const f32x4 c0 = acc[y][0], c1 = acc[y][1];
@@ -250,7 +255,8 @@ __device__ __forceinline__ void between_convs(const uint8_t* wlds, f32x4 (&acc)[
             FENCE();                                         // row by row: vector work of row y+1 under these MFMAs
         }
     }
-    w = n;
+    w = nx;
+    nx = n;
     FENCE();
 }
 
@@ -309,16 +315,16 @@ __device__ __forceinline__ void trunk_task(const uint8_t* wlds, const float* sbi
         const Bias2 b0 = lane_bias(sbias, lane);
         stem<NT>(wlds, pos, acc, b0, lane);
     }
-    WPair w = wload<0, 1, 1>(wlds, lane);
-    if (num_blocks > 0) between_convs<0, true, NT>(wlds, acc, X, b1, w, lane);
-    else between_convs<0, false, NT>(wlds, acc, X, b1, w, lane);
+    WPair w = wload<0, 1, 1>(wlds, lane), nx = wload<0, 0, 1>(wlds, lane);
+    if (num_blocks > 0) between_convs<0, true, NT>(wlds, acc, X, b1, w, nx, lane);
+    else between_convs<0, false, NT>(wlds, acc, X, b1, w, nx, lane);
 #pragma unroll 1
     for (int blk = 0; blk < num_blocks; ++blk) {
-        conv_rest<0, 1, false, NT>(wlds, X, X, acc, w, lane);
-        between_convs<1, true, NT>(wlds, acc, Y, b2, w, lane);
-        conv_rest<1, 0, true, NT>(wlds, Y, X, acc, w, lane);
-        if (blk + 1 < num_blocks) between_convs<0, true, NT>(wlds, acc, X, b1, w, lane);
-        else between_convs<0, false, NT>(wlds, acc, X, b1, w, lane);
+        conv_rest<0, 1, false, NT>(wlds, X, X, acc, w, nx, lane);
+        between_convs<1, true, NT>(wlds, acc, Y, b2, w, nx, lane);
+        conv_rest<1, 0, true, NT>(wlds, Y, X, acc, w, nx, lane);
+        if (blk + 1 < num_blocks) between_convs<0, true, NT>(wlds, acc, X, b1, w, nx, lane);
+        else between_convs<0, false, NT>(wlds, acc, X, b1, w, nx, lane);
     }
     // 1x1 head convs as one MFMA per tile: rows 0,1 of D = policy planes, row 2 = value plane, which land in the
     // lanes q = 0 (registers 0..2) of each position
