@@ -149,7 +149,7 @@ def test_cache_bad_size_rejected():
     eng.close()
 
 
-@pytest.mark.parametrize('G,S', [(512, 48), (8192, 24), (100, 33), (8, 20)])
+@pytest.mark.parametrize('G,S', [(512, 48), (8192, 24), (100, 33), (8, 20), (257, 12), (1, 40), (4000, 7)])
 def test_fused_move_equals_the_stepwise_loop(G, S):
     """az_c4_move_fused (a workgroup owns its games for the whole move, search and network in one launch)
     against the stepwise loop with az_c4net_bf16_forward: identical moves, visit counts, records, counters."""
@@ -195,7 +195,7 @@ def test_fused_move_equals_the_stepwise_loop(G, S):
             np.testing.assert_array_equal(w0, w1)
         assert out[0][1] == out[other][1]
         np.testing.assert_array_equal(out[0][2], out[other][2])
-    assert hits > 0
+    assert hits > 0 or G == 1              # (a single small tree may hold no transposition)
 
 
 @pytest.mark.parametrize('G,S', [(8192, 800), (1024, 200)])
