@@ -74,6 +74,20 @@ k_sgd(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ bu
     p[i] = fmaf(-lr, b, p[i]);
 }
 
+// the same with the learning rate read from device memory, for launches recorded once and replayed (a HIP graph
+// bakes scalar arguments in): buf must start as zeros, which makes the first step's buf = d without a flag
+__global__ void __launch_bounds__(256)
+k_sgd_lr_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, long n,
+             const float* __restrict__ lr_dev, float momentum, float wd) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float lr = lr_dev[0];
+    const float d = fmaf(wd, p[i], g[i]);
+    const float b = buf[i] * momentum + d;
+    buf[i] = b;
+    p[i] = fmaf(-lr, b, p[i]);
+}
+
 extern "C" {
 
 int az_loss_fwd_bwd(int32_t num_actions, const float* logits, const float* v_hat, const float* target, const float* z,
@@ -98,6 +112,16 @@ int az_sgd_momentum(float* params, const float* grads, float* momentum_buf, int6
     hipLaunchKernelGGL(k_sgd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grads,
                        momentum_buf, (long)n, lr, momentum, weight_decay, (int)first_step);
     AZ_LAUNCH_CHECK("k_sgd");
+    return 0;
+}
+
+int az_sgd_momentum_lr_dev(float* params, const float* grads, float* momentum_buf, int64_t n, const float* lr_dev,
+                           float momentum, float weight_decay, void* stream) {
+    if (n < 0 || !lr_dev || (n && (!params || !grads || !momentum_buf))) return az_fail("az_sgd_momentum_lr_dev: null pointer");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_sgd_lr_dev, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grads,
+                       momentum_buf, (long)n, lr_dev, momentum, weight_decay);
+    AZ_LAUNCH_CHECK("k_sgd_lr_dev");
     return 0;
 }
 

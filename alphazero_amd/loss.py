@@ -67,7 +67,11 @@ class AlphaZeroLoss(nn.Module):
     def forward(self, p, z, p_hat, v_hat, p_valid):
         if p_hat.is_cuda:
             policy_loss, value_loss, dev = _HipLoss.apply(p_hat, v_hat, p, z, p_valid)
-            assert float(dev.detach()) < 1e-6, f'Target policy must be a valid distribution: {p}'
+            self.target_deviation = dev.detach()       # max |sum(target) - 1| of this batch, on the device
+            if not torch.cuda.is_current_stream_capturing():
+                assert float(self.target_deviation) < 1e-6, f'Target policy must be a valid distribution: {p}'
+            # (while a HIP graph is being recorded nothing may be read back: whoever replays the graph checks
+            # target_deviation afterwards)
             return policy_loss, value_loss
         value_loss = ((z - v_hat) ** 2).mean()
         assert torch.all(torch.abs(p.sum(dim=1) - 1.) < 1e-6), \

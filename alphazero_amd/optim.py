@@ -41,6 +41,7 @@ class FlatSGD(torch.optim.Optimizer):
                 p.grad = self.flat_g[off:off + k].view_as(p)
                 off += k
         self._steps = 0
+        self._lr_dev = None                                # learning rate in device memory, for recorded steps
 
     def zero_grad(self, set_to_none=False):
         self.flat_g.zero_()                                # the .grad views stay in place
@@ -53,4 +54,28 @@ class FlatSGD(torch.optim.Optimizer):
             _lib.check(self.lib.az_sgd_momentum(_lib.ptr(self.flat_p), _lib.ptr(self.flat_g), _lib.ptr(self.flat_m),
                                                 self.flat_p.numel(), float(g['lr']), float(g['momentum']),
                                                 float(g['weight_decay']), int(self._steps == 0), st))
+        self._steps += 1
+
+    def set_recorded_lr(self):
+        """Puts the current learning rate where step_recorded's kernel reads it (a copy only when it changed)."""
+        lr = float(self.param_groups[0]['lr'])
+        if self._lr_dev is None:
+            self._lr_dev = torch.empty(1, dtype=torch.float32, device=self.device)
+            self._lr_host = None
+        if self._lr_host != lr:
+            self._lr_dev.fill_(lr)
+            self._lr_host = lr
+
+    @torch.no_grad()
+    def step_recorded(self):
+        """The same update with the learning rate read from device memory at run time (az_sgd_momentum_lr_dev):
+        the launch can be captured in a HIP graph and replayed while a scheduler changes the rate.  Call
+        set_recorded_lr() (outside the capture) before every run."""
+        g = self.param_groups[0]
+        assert self._lr_dev is not None, 'set_recorded_lr() first'
+        with torch.cuda.device(self.device):
+            st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            _lib.check(self.lib.az_sgd_momentum_lr_dev(_lib.ptr(self.flat_p), _lib.ptr(self.flat_g), _lib.ptr(self.flat_m),
+                                                       self.flat_p.numel(), _lib.ptr(self._lr_dev), float(g['momentum']),
+                                                       float(g['weight_decay']), st))
         self._steps += 1

@@ -333,7 +333,7 @@ class DeviceReplayWindow:
         return {'x': self.x[j], 'p': self.p[j], 'z': self.z[j], 'p_valid': self.p_valid[j],
                 'model_version': int(self.model_version[j])}
 
-    def sample(self, batch_size, generator=None):
+    def _sample_index(self, batch_size, generator=None):
         torch = self._torch
         n = len(self)
         if n == 0:
@@ -342,6 +342,19 @@ class DeviceReplayWindow:
             idx = torch.randint(n, (batch_size,), device=self.device, generator=generator)
         else:
             idx = torch.randperm(n, device=self.device, generator=generator)[:batch_size]
-        idx = (idx + (self.count - n)) % self.capacity
+        return (idx + (self.count - n)) % self.capacity
+
+    def sample(self, batch_size, generator=None):
+        idx = self._sample_index(batch_size, generator)
         return {'x': self.x[idx], 'p': self.p[idx], 'z': self.z[idx], 'p_valid': self.p_valid[idx],
                 'model_version': self.model_version[idx]}
+
+    def sample_into(self, x, p, z, p_valid, generator=None):
+        """The same draw as sample(len(x)), gathered into the caller's tensors (a training step recorded as a
+        HIP graph reads its batch from fixed addresses)."""
+        torch = self._torch
+        idx = self._sample_index(x.shape[0], generator)
+        torch.index_select(self.x, 0, idx, out=x)
+        torch.index_select(self.p, 0, idx, out=p)
+        torch.index_select(self.z, 0, idx, out=z)
+        torch.index_select(self.p_valid, 0, idx, out=p_valid)

@@ -2,7 +2,10 @@
 (alphazero/training.py:15-125): SGD + momentum + weight decay, MultiStepLR, masked
 cross-entropy + MSE, weights published after every step.  On the GPU the loss with its gradients and the
 optimiser update are hand-written kernels (loss.AlphaZeroLoss, optim.FlatSGD; csrc/az_train.hip); the network's
-forward and backward in between are PyTorch's.  The summary
+forward and backward in between are PyTorch's.  With a DeviceReplayWindow on the GPU the whole step (forward,
+loss, backward, update: about 300 small launches) is recorded once as a HIP graph after three ordinary steps and
+replayed from then on, the batch gathered into fixed tensors and the learning rate read from device memory
+(AZ_TRAIN_GRAPH=0 or record_step=False keeps every step eager).  The summary
 writer and model server are duck-typed (`add_scalar`, `update(model, version)`).  `dataset` is a
 ReplayBufferDataset (the reference's per-state sample dicts) or a DeviceReplayWindow (batches taken
 straight from tensors on the GPU)."""
@@ -17,8 +20,11 @@ from .replay_buffer import ReplayBufferSampler
 
 
 class TrainingWorker:
+    EAGER_STEPS = 3       # ordinary steps before the step is recorded (the libraries pick their kernels in them)
+    CHECK_EVERY = 16      # recorded steps between two read-backs of the target-distribution check
+
     def __init__(self, config, model_server, dataset, summary_writer, device, num_workers=0, grad_sync=None,
-                 batch_size=None):
+                 batch_size=None, record_step=None):
         self._config, self._model_server, self._dataset = config, model_server, dataset
         # data-parallel use: grad_sync(model) runs between backward() and the optimizer step (e.g.
         # distributed.allreduce_gradients) and batch_size is this rank's share of config's batch
@@ -39,6 +45,12 @@ class TrainingWorker:
         self._lr_schedule = MultiStepLR(self._optimizer, t['lr_schedule'], gamma=t['lr_schedule_gamma'])
         self._sampler = ReplayBufferSampler(dataset, batch_size=self._batch_size, bufferlen=64 * 1024)
         self._iter = 0
+        import os
+        if record_step is None:
+            record_step = os.environ.get('AZ_TRAIN_GRAPH', '1') != '0'
+        self._record = bool(record_step and torch.device(device).type == 'cuda' and hasattr(dataset, 'sample_into')
+                            and grad_sync is None and hasattr(self._optimizer, 'step_recorded'))
+        self._graph = None
 
     @property
     def model(self):
@@ -86,6 +98,8 @@ class TrainingWorker:
             print(f'Skipping batch, too few examples in replay buffer ({N} < {M}).')
             return 0
         self._model.train()
+        if self._record and self._iter >= self.EAGER_STEPS:
+            return self._process_batch_recorded()
         x, p, z, p_valid, extra = self._batch()
         p_hat, v_hat = self._model(x, p_valid)
         policy_loss, value_loss = self._loss(p, z, p_hat, v_hat, p_valid)
@@ -111,4 +125,49 @@ class TrainingWorker:
                 self._writer.add_scalar('data/total_games', db.num_games(), it)
                 self._writer.add_scalar('data/distinct_games', db.num_distinct_games(), it)
                 self._writer.add_scalar('data/total_states', db.num_states(), it)
+        return it + 1
+
+    # ---- the step as one recorded launch sequence ------------------------------------------------------------
+    def _record_step(self):
+        ds, B, dev = self._dataset, self._batch_size, self._device
+        self._gx = torch.empty((B,) + tuple(ds.x.shape[1:]), dtype=ds.x.dtype, device=dev)
+        self._gp = torch.empty((B,) + tuple(ds.p.shape[1:]), dtype=ds.p.dtype, device=dev)
+        self._gz = torch.empty((B,) + tuple(ds.z.shape[1:]), dtype=ds.z.dtype, device=dev)
+        self._gvalid = torch.empty((B,) + tuple(ds.p_valid.shape[1:]), dtype=ds.p_valid.dtype, device=dev)
+        ds.sample_into(self._gx, self._gp, self._gz, self._gvalid)
+        self._optimizer.set_recorded_lr()
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            p_hat, v_hat = self._model(self._gx, self._gvalid)
+            policy_loss, value_loss = self._loss(self._gp, self._gz, p_hat, v_hat, self._gvalid)
+            self._optimizer.zero_grad()
+            total = policy_loss + value_loss
+            total.backward()
+            self._optimizer.step_recorded()
+        self._graph = graph
+        self._g_out = (policy_loss.detach(), value_loss.detach(), total.detach())
+        return graph
+
+    def _process_batch_recorded(self):
+        if self._graph is None:
+            self._record_step()                       # (its batch is already in place)
+        else:
+            self._dataset.sample_into(self._gx, self._gp, self._gz, self._gvalid)
+        self._optimizer.set_recorded_lr()
+        self._graph.replay()
+        self._optimizer._opt_called = True            # what MultiStepLR looks at before it steps
+        self._lr_schedule.step()
+        it = self._iter
+        self._iter += 1
+        self._model_server.update(self._model, it + 1)
+        if self._writer is not None or it % self.CHECK_EVERY == 0:
+            dev = getattr(self._loss, 'target_deviation', None)
+            assert dev is None or float(dev) < 1e-6, 'Target policy must be a valid distribution'
+        if self._writer is not None:
+            policy_loss, value_loss, total = self._g_out
+            self._writer.add_scalar('loss/policy', policy_loss, it)
+            self._writer.add_scalar('loss/value', value_loss, it)
+            self._writer.add_scalar('loss/total', total, it)
+            self._writer.add_scalar('optim/learning_rate', self._lr_schedule.get_last_lr()[0], it)
         return it + 1

@@ -600,7 +600,7 @@ def main():
             # (c) BASELINE config 4
             out['config4_leaf_eval'] = config4_leaf_eval(dev)
             # (d) BASELINE config 5 on one GPU: the training step on the device-resident replay window, alone
-            # and inside the self-play loop (one SGD step and one weight hand-over per lock-step move, as the
+            # and inside the self-play loop (one SGD step and one weight hand-over per move of all games, as the
             # reference's synchronous mode alternates them, alphazero/train.py:86-96)
             from alphazero_amd.config import AlphaZeroConfig
             from alphazero_amd.games import ConnectFour
@@ -651,10 +651,11 @@ def main():
             dt = (time.perf_counter() - t1) / loop_steps
             out['config5_train_loop'] = {
                 'training_step_ms': train_ms, 'batch_size': 128, 'samples_per_s': 128 / (train_ms * 1e-3),
-                'step': 'sample from the device window + forward + az_loss_fwd_bwd + backward + az_sgd_momentum + publish',
+                'step': 'sample from the device window + forward + az_loss_fwd_bwd + backward + az_sgd_momentum + publish; '
+                        'forward .. update replayed as one recorded HIP graph',
                 'selfplay_with_training': {'value': G / dt, 'unit': 'positions/s', 'ms_per_step': 1e3 * dt,
                                            'steps': loop_steps,
-                                           'per_step': 'one lock-step move (records stay on the device) + one SGD step + '
+                                           'per_step': 'one move of every game (records stay on the device) + one SGD step + '
                                                        're-pack of the weights for the self-play kernels'},
                 'window_states': len(window), 'note': 'one GPU; with N ranks the records are gathered on the trainer rank '
                                                       'and the packed weights broadcast (see config.exchange)'}

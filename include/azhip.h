@@ -319,6 +319,11 @@ int  az_loss_fwd_bwd(int32_t num_actions, const float* logits, const float* v_ha
                      const uint8_t* valid, int32_t batch, float* out3, float* dlogits, float* dv, void* stream);
 int  az_sgd_momentum(float* params, const float* grads, float* momentum_buf, int64_t n, float lr, float momentum,
                      float weight_decay, int32_t first_step, void* stream);
+/* az_sgd_momentum with the learning rate read from DEVICE memory (lr_dev float[1]) when the kernel runs, so that
+ * the launch can be recorded once in a HIP graph and replayed while a schedule (training.py:30-31, MultiStepLR)
+ * changes the rate; momentum_buf must start as zeros (then the first step's buf = d, as torch.optim.SGD's).   */
+int  az_sgd_momentum_lr_dev(float* params, const float* grads, float* momentum_buf, int64_t n, const float* lr_dev,
+                            float momentum, float weight_decay, void* stream);
 
 #ifdef __cplusplus
 }

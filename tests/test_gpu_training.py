@@ -121,3 +121,56 @@ def test_training_steps_on_the_gpu_match_the_reference_scalars():
         a, b = state[k].detach().cpu().numpy().reshape(-1), unhex(h, '<f4')
         assert np.allclose(a, b, rtol=1e-4, atol=1e-5), (k, np.abs(a - b).max())
     print('worst relative scalar error vs the reference:', worst)
+
+
+def test_recorded_training_step_equals_the_eager_one():
+    """TrainingWorker on a DeviceReplayWindow records its step as a HIP graph after three eager steps
+    (training.TrainingWorker._record_step).  Two workers from the same seeds, one recording and one not, must draw the
+    same batches and end with the same weights, batch-norm statistics and logged losses, across a change of the
+    learning rate by the schedule (the recorded update reads the rate from device memory)."""
+    from alphazero_amd import engine as E
+    from alphazero_amd.config import AlphaZeroConfig
+    from alphazero_amd.games import ConnectFour
+    from alphazero_amd.replay_buffer import DeviceReplayWindow
+    from alphazero_amd.training import TrainingWorker
+    cfg = AlphaZeroConfig(conf={
+        'game': {'module': 'alphazero.games.connectfour', 'name': 'ConnectFour'},
+        'model': {'module': 'alphazero.games.connectfour', 'name': 'AlphaZeroC4',
+                  'kwargs': {'num_blocks': 2, 'channels_per_block': 16}},
+        'loss': {'module': 'alphazero.loss', 'name': 'AlphaZeroLoss'},
+        'training': {'num_steps': 100, 'batch_size': 32, 'lr': 0.1, 'momentum': 0.9, 'weight_decay': 1e-4,
+                     'lr_schedule_gamma': 0.1, 'lr_schedule': [6]}})
+    dev = torch.device('cuda:0')
+    eng = E.SelfPlayEngine(E._lib.GAME_C4, 256, 16, exploration_depth=4, reuse_search_tree=True, seed=5, device=0)
+    window = DeviceReplayWindow(ConnectFour, 4096, dev)
+    while len(window) < 512:
+        eng.begin_move_uniform(); eng.run_sims_uniform(16); eng.choose_and_advance()
+        window.add_records(eng.drain_finished_bytes())
+
+    class Server:
+        def update(self, model, version):
+            pass
+
+    class Writer:
+        def __init__(self):
+            self.rows = []
+
+        def add_scalar(self, tag, value, step):
+            self.rows.append((tag, float(value), int(step)))
+
+    runs = []
+    for record in (False, True):
+        torch.manual_seed(11)
+        writer = Writer()
+        tw = TrainingWorker(cfg, Server(), window, writer, dev, record_step=record)
+        assert tw._record == record
+        assert [tw.process_batch() for _ in range(10)] == list(range(1, 11))
+        assert (tw._graph is not None) == record
+        runs.append((writer.rows, {k: v.detach().clone() for k, v in tw.model.state_dict().items()}))
+    (rows_a, sd_a), (rows_b, sd_b) = runs
+    assert [(r[0], r[2]) for r in rows_a] == [(r[0], r[2]) for r in rows_b]
+    for ra, rb in zip(rows_a, rows_b):
+        assert abs(ra[1] - rb[1]) <= 1e-6 * max(1.0, abs(ra[1])), (ra, rb)
+    assert any(r[0] == 'optim/learning_rate' and abs(r[1] - 0.01) < 1e-9 for r in rows_b)      # the schedule stepped
+    for k in sd_a:
+        assert torch.allclose(sd_a[k].float(), sd_b[k].float(), rtol=1e-5, atol=1e-6), (k, (sd_a[k].float() - sd_b[k].float()).abs().max())
