@@ -643,10 +643,18 @@ def main():
             t1 = time.perf_counter()
             loop_steps = 4
             for _ in range(loop_steps):
-                play_and_collect()
+                # the SGD step and the re-pack are queued behind the move before the host waits for the move's
+                # records, so the device goes from one to the other without idling (an idle device drops its clocks
+                # and the 1.5 ms step then takes 5-10 ms: tools/train_loop_probe.py); the step therefore trains on the
+                # window as it was one move earlier
+                one_step(False)
                 v_new = tw.process_batch()
                 fused.load_module(tw.model)                  # the new weights reach the self-play kernels
                 eng.set_model_version(v_new)
+                recs, head = eng.take_finished_device()
+                n_rec, flags = head.tolist()
+                assert flags == 0
+                window.add_records_device(recs[:n_rec])
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t1) / loop_steps
             out['config5_train_loop'] = {

@@ -68,6 +68,10 @@ for _ in range(N):
     part('move', move)
     recs = part('take finished', collect)
     part('window update', lambda: window.add_records_device(recs))
+    if os.environ.get('AZ_SLEEP'):
+        time.sleep(float(os.environ['AZ_SLEEP']) * 1e-3)
+    if os.environ.get('AZ_TOUCH'):
+        part('touch', lambda: (window.x.sum(), tw._optimizer.flat_p.sum()))
     v_new = part('sgd step', tw.process_batch)
     if os.environ.get('AZ_TWICE'):
         part('sgd step again', tw.process_batch)
