@@ -848,26 +848,38 @@ __global__ void __launch_bounds__(1024) k_fused_balance(Dev E, int gpw, int grid
 //     ready queue --a wave's search step: (expand/backup of the last evaluation,) select-->
 //         leaf queue    (the leaf needs the network)
 //         ready queue   (terminal leaf, backed up at once; or the evaluation was found in the cache)
-//     leaf queue --a wave's network task: tower + heads of two queued leaves (one if no other is in sight)-->
-//         ready queue
-// until the expand/backup that follows its num_sims-th select.  The eight waves are identical workers:
-// a worker takes a network task when two leaves are queued, otherwise up to eight ready games for one
-// search step (eight lanes per tree), otherwise it sleeps.  So the tree walks' memory latency hides behind
-// other games' matrix work, each SIMD has a second wave's MFMA stream to fill the gaps of the first
-// most of the time, and no wave ever waits for a whole round of leaves to be complete: there is no
+//     leaf queue --a wave's network task: stem, tower and head convs of two queued leaves (one if no other is
+//         in sight) in the wave's registers, head planes into the games' slots in LDS--> plane queue
+//     plane queue --one wave: the fully connected heads of ALL boards that wait, up to 32 columns of the
+//         same MFMAs--> (p, v), ready queue
+// until the expand/backup that follows its num_sims-th select.  The eight waves are identical workers: a
+// worker takes a network task when two leaves are queued; else the heads, if eight boards wait for them (or any,
+// when there is nothing to search) and no other wave is at it; else up to eight ready games for one search
+// step (eight lanes per tree); else it sleeps.  So the tree walks' memory latency hides behind other games'
+// matrix work, each SIMD has a second wave's MFMA stream to fill the gaps of the first most of the time, the
+// heads (latency-bound chains that cost a wave the same for 32 boards as for two) are paid once per six
+// boards on average, and no wave ever waits for a whole round of leaves to be complete: there is no
 // workgroup barrier after the set-up.  A game's own sequence select -> evaluate -> expand/backup is what it
-// is in the lock-step kernels and the network's outputs do not depend on which leaf shares a task, so
-// trees, visit counts and records are bit-identical to the two-kernel path.
+// is in the lock-step kernels and the network's outputs do not depend on which leaf shares a task or a head
+// batch, so trees, visit counts and records are bit-identical to the two-kernel path.
 // Hand-offs: (p, v), slots, nodes and leaf positions are written, then a workgroup-scope release fence, then
 // the queue entry (LDS atomics); the taker reads the entry, then an acquire fence.  A queue is a ring of
 // FUSED_QUEUE words (game + 1, 0 = its writer has the slot but has not stored yet) with a head and a tail
-// counter; a game has at most one entry in both queues together, so the rings never wrap onto live entries.
+// counter; a game has at most one entry in the three queues together, so the rings never wrap onto live entries.
 // A worker that finds nothing to do for WATCHDOG_SPINS polls in a row gives up (a fault elsewhere must not
 // hang the GPU): it sets the abort word, every wave leaves, and bit 4 of the engine's error flags reports it.
 // ---------------------------------------------------------------------------
 #define FUSED_QUEUE 64                 // ring slots >= games per workgroup
+#ifndef FUSED_HEADS_MIN
+#define FUSED_HEADS_MIN 8              // boards waiting for their heads from which a worker prefers them to a search step
+#endif
+// the games' head planes live behind the network scratch: one slot per game
+#define FX_PLANES S_BYTES
+#define FX_END (FX_PLANES + 64 * PLANE_SLOT)
+#define FUSED_LDS_BYTES (OFF_BIAS + FX_END)
 #define WATCHDOG_SPINS (1 << 20)       // x >= 128 cycles per poll: far beyond any wait of a healthy launch
-enum { FC_LEAF_HEAD = 0, FC_LEAF_TAIL, FC_DONE, FC_ABORT, FC_READY_HEAD, FC_READY_TAIL, FC_SEARCHING, FC_GAMES };
+enum { FC_LEAF_HEAD = 0, FC_LEAF_TAIL, FC_DONE, FC_ABORT, FC_READY_HEAD, FC_READY_TAIL, FC_SEARCHING, FC_GAMES,
+       FC_PLANES_HEAD, FC_PLANES_TAIL, FC_HEADS_LOCK };
 
 __device__ __forceinline__ int lds_load(const int* a) {
     return __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -912,7 +924,7 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     {
         uint4* z = reinterpret_cast<uint4*>(scr);
-        for (int i = tid; i < S_BYTES / 16; i += NTHREADS) z[i] = make_uint4(0, 0, 0, 0);
+        for (int i = tid; i < FX_END / 16; i += NTHREADS) z[i] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
     if (tid < 99) reinterpret_cast<float*>(scr + S_BIAS)[tid] = reinterpret_cast<const float*>(blob + OFF_BIAS)[tid];
@@ -930,8 +942,11 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
     int* gmap = nsel + 64;                                               // [64] the workgroup's games (E.order)
     int* leafq = reinterpret_cast<int*>(scr + S_LG + 32 * 64 * 4);       // [FUSED_QUEUE]
     int* readyq = leafq + FUSED_QUEUE;                                   // [FUSED_QUEUE]
+    int* planeq = readyq + FUSED_QUEUE;                                  // [FUSED_QUEUE] boards waiting for their heads
+    int* batch = planeq + FUSED_QUEUE;                                   // [32] the boards of the head batch in flight
+    uint8_t* planes = scr + FX_PLANES;                                   // [64][PLANE_SLOT]
     int* ctr = reinterpret_cast<int*>(scr + S_WT);                       // FC_* words
-    static_assert(8 * MAXIT * 2 >= 128 && 2 * FUSED_QUEUE * 4 <= 8 * 32 * 4, "LDS areas reused by the hand-off words");
+    static_assert(8 * MAXIT * 2 >= 128 && (3 * FUSED_QUEUE + 32) * 4 <= 8 * 32 * 4, "LDS areas reused by the hand-off words");
     uint64_t* lbb = reinterpret_cast<uint64_t*>(scr + S_LBB);            // [64][2] leaf positions
     const int wave_id = (int)blockIdx.x * (NTHREADS / 64) + wave;
     if (wave == 0) {
@@ -947,9 +962,6 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
     const int n_valid = ctr[FC_GAMES];
 
     const float* sbias = reinterpret_cast<const float*>(scr + S_BIAS);
-    uint8_t* pw = scr + S_PW + wave * PW_BYTES;
-    __bf16* hp = reinterpret_cast<__bf16*>(pw + PW_HP);
-    __bf16* hv = reinterpret_cast<__bf16*>(pw + PW_HV);
     const int sub = lane & (GS - 1);
 
     // one search step of game gl by this lane's group of eight
@@ -973,7 +985,7 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
 
 #ifdef AZ_EXP_TIMING     // tuning aid (tools/exp_fused_timing.py): what the waves spend their cycles on
     long long t_task = 0, t_search = 0, t_idle = 0, t_heads = 0, t_fence = 0, t0 = clock64(), t1;
-    unsigned long long n_pair = 0, n_single = 0, n_step = 0, n_stepped = 0;
+    unsigned long long n_pair = 0, n_single = 0, n_step = 0, n_stepped = 0, n_hbatch = 0;
 #define TICK(acc) do { t1 = clock64(); acc += t1 - t0; t0 = t1; } while (0)
 #else
 #define TICK(acc) do { } while (0)
@@ -982,33 +994,65 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
         if (uni(lds_load(ctr + FC_ABORT)) || uni(lds_load(ctr + FC_DONE)) >= n_valid) break;
         const int lh = uni(lds_load(ctr + FC_LEAF_HEAD)), leaves = uni(lds_load(ctr + FC_LEAF_TAIL)) - lh;
         const int rh = uni(lds_load(ctr + FC_READY_HEAD)), ready = uni(lds_load(ctr + FC_READY_TAIL)) - rh;
-        // a lone leaf is taken only when no second one can turn up soon: nothing ready, nothing being searched
-        if (leaves >= 2 || (leaves == 1 && ready <= 0 && uni(lds_load(ctr + FC_SEARCHING)) == 0)) {
+        const int ph = uni(lds_load(ctr + FC_PLANES_HEAD)), waiting = uni(lds_load(ctr + FC_PLANES_TAIL)) - ph;
+        // a lone leaf is taken only when no second one can turn up soon: nothing ready, nothing being searched or
+        // waiting for its heads
+        if (leaves >= 2 || (leaves == 1 && ready <= 0 && waiting <= 0 && uni(lds_load(ctr + FC_SEARCHING)) == 0)) {
             const int take = leaves >= 2 ? 2 : 1;
             if (!ring_claim(ctr + FC_LEAF_HEAD, lh, take, lane)) continue;
             TICK(t_idle);
             const int g0 = ring_take(leafq, lh, lane), g1 = take == 2 ? ring_take(leafq, lh + 1, lane) : -1;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            __bf16* hp0 = reinterpret_cast<__bf16*>(planes + g0 * PLANE_SLOT);
             if (g1 >= 0) {
                 const int g_mine = (lane & 8) ? g1 : g0;
-                trunk_task<ROWS>(wlds, sbias, num_blocks, lbb + 2 * g_mine, hp, hv, 0, lane);
+                __bf16* hp1 = reinterpret_cast<__bf16*>(planes + g1 * PLANE_SLOT);
+                trunk_task<ROWS>(wlds, sbias, num_blocks, lbb + 2 * g_mine, hp0, hp0 + 96, hp1, hp1 + 96, lane);
             } else {
-                trunk_task<ROWS / 2>(wlds, sbias, num_blocks, lbb + 2 * g0, hp, hv, 0, lane);
+                trunk_task<ROWS / 2>(wlds, sbias, num_blocks, lbb + 2 * g0, hp0, hp0 + 96, nullptr, nullptr, lane);
             }
-#ifdef AZ_EXP_TIMING
-            TICK(t_task);
-#endif
-            heads_wave(wlds, scr, wave, lane, gmap[g0], g1 >= 0 ? gmap[g1] : -1, lbb + 2 * g0,
-                       lbb + 2 * (g1 >= 0 ? g1 : g0), p, v);
-            TICK(t_heads);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // the planes, before the boards are queued
             if (lane == 0) {
-                ring_push(readyq, ctr + FC_READY_TAIL, g0);
-                if (g1 >= 0) ring_push(readyq, ctr + FC_READY_TAIL, g1);
+                ring_push(planeq, ctr + FC_PLANES_TAIL, g0);
+                if (g1 >= 0) ring_push(planeq, ctr + FC_PLANES_TAIL, g1);
             }
-            TICK(t_fence);
+            TICK(t_task);
 #ifdef AZ_EXP_TIMING
             if (g1 >= 0) ++n_pair; else ++n_single;
+#endif
+            spins = 0;
+            continue;
+        }
+        // The fully connected heads of all boards that wait for them, at most 32, by one wave at a time: a batch costs
+        // what two boards cost.  Preferred to a search step once FUSED_HEADS_MIN boards wait, else taken when there
+        // is nothing to search.
+        if ((waiting >= FUSED_HEADS_MIN || (waiting > 0 && ready <= 0)) && uni(lds_load(ctr + FC_HEADS_LOCK)) == 0 &&
+            ring_claim(ctr + FC_HEADS_LOCK, 0, 1, lane)) {
+            // (only the holder of the lock moves this ring's head)
+            const int ph2 = uni(lds_load(ctr + FC_PLANES_HEAD));
+            int n = uni(lds_load(ctr + FC_PLANES_TAIL)) - ph2;
+            n = n < 32 ? n : 32;
+            TICK(t_idle);
+            if (n > 0) {
+                if (lane == 0) { lds_store(ctr + FC_PLANES_HEAD, ph2 + n); lds_add(ctr + FC_SEARCHING, n); }
+                if (lane < n) {
+                    int* slot = planeq + ((ph2 + lane) & (FUSED_QUEUE - 1));
+                    int x;
+                    while ((x = lds_load(slot)) == 0) __builtin_amdgcn_s_sleep(1);      // its writer is one store behind
+                    lds_store(slot, 0);
+                    batch[lane] = x - 1;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                heads_batch(wlds, scr, planes, batch, n, gmap, lbb, p, v, lane);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // (p, v), before the games are queued
+                if (lane < n) ring_push(readyq, ctr + FC_READY_TAIL, batch[lane]);
+                if (lane == 0) lds_add(ctr + FC_SEARCHING, -n);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) lds_store(ctr + FC_HEADS_LOCK, 0);
+            TICK(t_heads);
+#ifdef AZ_EXP_TIMING
+            ++n_hbatch;
 #endif
             spins = 0;
             continue;
@@ -1065,6 +1109,7 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
         atomicAdd(&g_net_dbg[3], n_stepped);
         atomicMax(&g_net_dbg[4], (unsigned long long)(t_task + t_heads + t_fence + t_search + t_idle));
         atomicAdd(&g_net_dbg[6], (unsigned long long)t_fence);
+        atomicAdd(&g_net_dbg[7], n_hbatch);
         atomicAdd(&g_net_dbg[5], (unsigned long long)t_heads);
     }
 #endif
@@ -1417,7 +1462,7 @@ static std::atomic<unsigned long long> g_fused_attr_done{0};        // bit d = k
 // with device `dev` current: look the array's address up once per device, and give the kernel its dynamic-LDS
 // attribute here, so that az_c4_move_fused_static itself is nothing but a launch
 static int scratch_setup(int dev) {
-    if (int rc = az_set_kernel_lds(reinterpret_cast<const void*>(k_c4_move_fused), LDS_BYTES, g_fused_attr_done)) return rc;
+    if (int rc = az_set_kernel_lds(reinterpret_cast<const void*>(k_c4_move_fused), FUSED_LDS_BYTES, g_fused_attr_done)) return rc;
     if (dev < 0 || dev >= MAX_DEVICES) return 0;                    // az_c4_move_fused_static refuses such a device
     if (g_scratch_ptr[dev]) return 0;
     void* ptr = nullptr;
@@ -1670,10 +1715,10 @@ static int fused_launch(az_engine* e, const uint8_t* blob, int32_t num_blocks, u
     if (gpw > FUSED_MAX_GPW) return az_fail("az_c4_move_fused: more than 64 games per compute unit");
     const int grid = (e->d.G + gpw - 1) / gpw;
     // already done by az_engine_create on this device (a bitmap test, then nothing)
-    if (int rc = az_set_kernel_lds(reinterpret_cast<const void*>(k_c4_move_fused), LDS_BYTES, g_fused_attr_done)) return rc;
+    if (int rc = az_set_kernel_lds(reinterpret_cast<const void*>(k_c4_move_fused), FUSED_LDS_BYTES, g_fused_attr_done)) return rc;
     if (e->d.G > BALANCE_MAX_GAMES) return az_fail("az_c4_move_fused: more than 16384 games");
     hipLaunchKernelGGL(k_fused_balance, dim3(1), dim3(1024), 0, st, e->d, gpw, grid);
-    hipLaunchKernelGGL(k_c4_move_fused, dim3(grid), dim3(NTHREADS), LDS_BYTES, st, e->d, blob, (int)num_blocks, leaf_bb,
+    hipLaunchKernelGGL(k_c4_move_fused, dim3(grid), dim3(NTHREADS), FUSED_LDS_BYTES, st, e->d, blob, (int)num_blocks, leaf_bb,
                        leaf_info, p, v, (int)e->d.S, gpw);
     AZ_LAUNCH_CHECK("k_c4_move_fused");
     return 0;

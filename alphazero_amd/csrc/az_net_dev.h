@@ -303,11 +303,12 @@ __device__ __forceinline__ void stem(const uint8_t* wlds, const uint64_t* pos /*
 }
 
 // One task from the bitboards to the head planes: stem, tower, 1x1 head convs.  pos = this lane's board (the
-// lane's half of a two-board task, or the one board of a folded task), null when there is none; planes of board
-// slot bl0 (+1 for the second board) of this wave's scratch receive the ReLU'd head-conv outputs.
+// lane's half of a two-board task, or the one board of a folded task), null when there is none; hp0 / hv0 (and
+// hp1 / hv1 for the second board) receive the ReLU'd head-conv outputs: 2 x 42 policy-plane values, 42 value-plane
+// values (bf16).
 template <int NT>
 __device__ __forceinline__ void trunk_task(const uint8_t* wlds, const float* sbias, int num_blocks, const uint64_t* pos,
-                                           __bf16* hp, __bf16* hv, int bl0, int lane) {
+                                           __bf16* hp0, __bf16* hv0, __bf16* hp1, __bf16* hv1, int lane) {
     bf16x8 X[NT], Y[NT];
     f32x4 acc[NT][2];
     const Bias2 b1 = lane_bias(sbias + 32, lane), b2 = lane_bias(sbias + 64, lane);
@@ -330,41 +331,47 @@ __device__ __forceinline__ void trunk_task(const uint8_t* wlds, const float* sbi
     // lanes q = 0 (registers 0..2) of each position
     const bf16x8 ah = frag_ptr(wlds, OFF_HF, lane)[0];
     const int p = lane & 15, x = p & 7;
-    const int bl = NT == ROWS ? bl0 + (p >> 3) : bl0, row0 = NT == ROWS ? 0 : 3 * (p >> 3);
+    const int row0 = NT == ROWS ? 0 : 3 * (p >> 3);
+    __bf16* hp = (NT == ROWS && (p >> 3)) ? hp1 : hp0;          // this lane's board
+    __bf16* hv = (NT == ROWS && (p >> 3)) ? hv1 : hv0;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
         const f32x4 d = MFMA16(ah, X[t], z4);
         if (lane < 16 && x != 7) {
             const int cell = (t + row0) * 7 + x;
-            hp[bl * 96 + cell] = (__bf16)fmaxf(d[0] + sbias[96], 0.0f);
-            hp[bl * 96 + 42 + cell] = (__bf16)fmaxf(d[1] + sbias[97], 0.0f);
-            hv[bl * 48 + cell] = (__bf16)fmaxf(d[2] + sbias[98], 0.0f);
+            hp[cell] = (__bf16)fmaxf(d[0] + sbias[96], 0.0f);
+            hp[42 + cell] = (__bf16)fmaxf(d[1] + sbias[97], 0.0f);
+            hv[cell] = (__bf16)fmaxf(d[2] + sbias[98], 0.0f);
         }
     }
 }
 
-// The fully connected heads of the (up to two) boards whose planes this wave has just left in board slots 0, 1 of
-// its own scratch, with no other wave involved: value FC 42->256->1 + tanh and policy FC 84->42 + landing-cell
-// gather + soft-max, the same arithmetic in the same order as the workgroup-wide head phase of net_rounds (whose
-// 32 MFMA columns are four boards of eight waves; here every column repeats slot 0 or 1), so the results are
-// bit-identical.  g0 / g1 = leaf indices (g1 < 0: none), pos0 / pos1 their positions.  The logits pass through the
-// wave's own four rows of scr + S_LG.
-__device__ __forceinline__ void heads_wave(const uint8_t* wlds, uint8_t* scr, int wave, int lane, int g0, int g1,
-                                           const uint64_t* pos0, const uint64_t* pos1, float* p_out, float* v_out) {
+// The fully connected heads of up to 32 boards at once, by ONE wave: value FC 42->256->1 + tanh and policy FC
+// 84->42 + landing-cell gather + soft-max, the same arithmetic in the same order as the workgroup-wide head phase
+// of net_rounds (each board is a column of the same 32x32x16 MFMAs), so the results are bit-identical.  A batch
+// costs the wave what two boards cost (the weights are read and the MFMAs issued once for all 32 columns).
+//   planes  LDS, one slot of PLANE_SLOT bytes per game: 96 bf16 policy planes (k = ch*42 + cell, 84 used) then
+//           48 bf16 value plane (42 used); the padding stays zero
+//   batch   LDS int[32]: local game index of column c < n;  gmap: LDS, leaf index (row of p_out / v_out) of a
+//           local game;  lbb: LDS, the games' leaf positions.  The logits pass through scr + S_LG.
+#define PLANE_SLOT 288
+__device__ __forceinline__ void heads_batch(const uint8_t* wlds, uint8_t* scr, const uint8_t* planes, const int* batch,
+                                            int n, const int* gmap, const uint64_t* lbb, float* p_out, float* v_out,
+                                            int lane) {
     const float* sbias = reinterpret_cast<const float*>(scr + S_BIAS);
     const float* sb1 = reinterpret_cast<const float*>(scr + S_B1);
     const float* sw2 = reinterpret_cast<const float*>(scr + S_W2);
     const float* sbp = reinterpret_cast<const float*>(scr + S_BP);
-    const uint8_t* pw = scr + S_PW + wave * PW_BYTES;
-    float* lg = reinterpret_cast<float*>(scr + S_LG) + wave * 4 * 64;
+    float* lg = reinterpret_cast<float*>(scr + S_LG);          // [32 boards][64]
     const int hh = lane >> 5, c = lane & 31;
-    const __bf16* chp = reinterpret_cast<const __bf16*>(pw + PW_HP) + (c & 1) * 96;
-    const __bf16* chv = reinterpret_cast<const __bf16*>(pw + PW_HV) + (c & 1) * 48;
+    const int my_game = batch[c < n ? c : 0];                  // (columns past n repeat column 0)
+    const __bf16* chp = reinterpret_cast<const __bf16*>(planes + my_game * PLANE_SLOT);
+    const __bf16* chv = chp + 96;
     // One wave alone has nobody to hide its LDS latency behind, so every group of operands is requested in one
     // batch, a scheduling fence keeps the batch together, and the arithmetic follows.
 #define HEADS_FENCE() __builtin_amdgcn_sched_barrier(0)
-    float sv = 0.0f;                                           // column c & 1: sum over the eight row tiles, in order
+    float sv = 0.0f;                                           // column c: sum over the eight row tiles, in order
     bf16x8 bv[3];
 #pragma unroll
     for (int s = 0; s < 3; ++s) bv[s] = *reinterpret_cast<const bf16x8*>(chv + 16 * s + 8 * hh);
@@ -433,7 +440,7 @@ __device__ __forceinline__ void heads_wave(const uint8_t* wlds, uint8_t* scr, in
         for (int s = 0; s < 6; ++s)
 #pragma unroll
             for (int hn = 0; hn < 2; ++hn) pacc[hn] = MFMA(pf[hn][s], bp8[s], pacc[hn]);
-        if (c < 2) {
+        if (c < n) {
 #pragma unroll
             for (int hn = 0; hn < 2; ++hn)
 #pragma unroll
@@ -447,13 +454,12 @@ __device__ __forceinline__ void heads_wave(const uint8_t* wlds, uint8_t* scr, in
     }
 #undef HEADS_FENCE
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");     // this wave's logits, before its own reads below
-    if (lane < 16) {
-        // landing-cell gather (connectfour.py:56-71) + soft-max over legal columns (mcts.py:106)
-        const int b = lane >> 3, col = lane & 7;
-        const int gidx = b ? g1 : g0;
-        const uint64_t* pos = b ? pos1 : pos0;
-        uint64_t occ = 0;
-        if (gidx >= 0) occ = pos[0] | pos[1];
+#pragma unroll 1
+    for (int b = lane >> 3; b < n; b += 8) {
+        // landing-cell gather (connectfour.py:56-71) + soft-max over legal columns (mcts.py:106): 8 lanes per board
+        const int col = lane & 7, gl = batch[b];
+        const uint64_t* pos = lbb + 2 * gl;
+        const uint64_t occ = pos[0] | pos[1];
         const int height = col < 7 ? __popcll((occ >> (7 * col)) & 0x3Full) : 6;
         const bool legal = col < 7 && height < 6;
         const float logit = legal ? lg[b * 64 + height * 7 + col] : -INFINITY;
@@ -462,12 +468,9 @@ __device__ __forceinline__ void heads_wave(const uint8_t* wlds, uint8_t* scr, in
         const float e = legal ? __expf(logit - m) : 0.0f;
         float sum = e;
         sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
-        if (col < 7 && gidx >= 0) p_out[(size_t)gidx * 7 + col] = legal ? e / sum : 0.0f;
+        if (col < 7) p_out[(size_t)gmap[gl] * 7 + col] = legal ? e / sum : 0.0f;
     }
-    if (lane < 2) {
-        const int gidx = lane ? g1 : g0;
-        if (gidx >= 0) v_out[gidx] = tanhf(sv + sbias[99]);
-    }
+    if (lane < n) v_out[gmap[batch[lane]]] = tanhf(sv + sbias[99]);
 }
 
 #ifdef AZ_EXP_TIMING     // tuning aid: shader cycles per part of the network phase, summed over waves
@@ -534,9 +537,11 @@ __device__ __forceinline__ void net_rounds(const uint8_t* blob, int num_blocks, 
             if (half) { hg2 = g_first; hg3 = g_second; } else { hg0 = g_first; hg1 = g_second; }
             if (g_second >= 0) {
                 const int g_mine = (lane & 8) ? g_second : g_first;
-                trunk_task<ROWS>(wlds, sbias, num_blocks, position(g_mine), hp, hv, 2 * half, lane);
+                trunk_task<ROWS>(wlds, sbias, num_blocks, position(g_mine), hp + 2 * half * 96, hv + 2 * half * 48,
+                                 hp + (2 * half + 1) * 96, hv + (2 * half + 1) * 48, lane);
             } else {
-                trunk_task<ROWS / 2>(wlds, sbias, num_blocks, position(g_first), hp, hv, 2 * half, lane);
+                trunk_task<ROWS / 2>(wlds, sbias, num_blocks, position(g_first), hp + 2 * half * 96, hv + 2 * half * 48,
+                                     nullptr, nullptr, lane);
             }
             NTICK(1);
         }

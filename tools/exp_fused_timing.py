@@ -33,4 +33,4 @@ for i in range(12):
     print(f'move {i}: launch {ms:.2f} ms; per wave: total {tot:.0f} cycles ({tot / (ms * 1e3):.0f} MHz), slowest {d[4]}; '
           f'towers {out[0] / n / tot:.1%} heads {d[5] / n / tot:.1%} hand-over {d[6] / n / tot:.1%} search {out[1] / n / tot:.1%} idle {out[2] / n / tot:.1%}')
     print(f'   tasks: {d[0]} pairs ({out[0] / max(d[0] + d[1], 1):.0f} + {d[5] / max(d[0] + d[1], 1):.0f} cycles per task incl. singles), {d[1]} singles; '
-          f'search steps {d[2]} with {d[3] / max(d[2], 1):.2f} games each, {out[1] / max(d[2], 1):.0f} cycles per step')
+          f'head batches {d[7]} with {(2 * d[0] + d[1]) / max(d[7], 1):.1f} boards each, {d[5] / max(d[7], 1):.0f} cycles per batch; search steps {d[2]} with {d[3] / max(d[2], 1):.2f} games each, {out[1] / max(d[2], 1):.0f} cycles per step')
