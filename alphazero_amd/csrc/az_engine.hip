@@ -866,8 +866,9 @@ __global__ void __launch_bounds__(1024) k_fused_balance(Dev E, int gpw, int grid
 // the queue entry (LDS atomics); the taker reads the entry, then an acquire fence.  A queue is a ring of
 // FUSED_QUEUE words (game + 1, 0 = its writer has the slot but has not stored yet) with a head and a tail
 // counter; a game has at most one entry in the three queues together, so the rings never wrap onto live entries.
-// A worker that finds nothing to do for WATCHDOG_SPINS polls in a row gives up (a fault elsewhere must not
-// hang the GPU): it sets the abort word, every wave leaves, and bit 4 of the engine's error flags reports it.
+// A worker that finds nothing to do for WATCHDOG_SPINS polls in a row during which no wave of the workgroup
+// finished anything gives up (a fault elsewhere must not hang the GPU): it sets the abort word, every wave
+// leaves, and bit 4 of the engine's error flags reports it.
 // ---------------------------------------------------------------------------
 #define FUSED_QUEUE 64                 // ring slots >= games per workgroup
 #ifndef FUSED_HEADS_MIN
@@ -879,7 +880,7 @@ __global__ void __launch_bounds__(1024) k_fused_balance(Dev E, int gpw, int grid
 #define FUSED_LDS_BYTES (OFF_BIAS + FX_END)
 #define WATCHDOG_SPINS (1 << 20)       // x >= 128 cycles per poll: far beyond any wait of a healthy launch
 enum { FC_LEAF_HEAD = 0, FC_LEAF_TAIL, FC_DONE, FC_ABORT, FC_READY_HEAD, FC_READY_TAIL, FC_SEARCHING, FC_GAMES,
-       FC_PLANES_HEAD, FC_PLANES_TAIL, FC_HEADS_LOCK };
+       FC_PLANES_HEAD, FC_PLANES_TAIL, FC_HEADS_LOCK, FC_PROGRESS };
 
 __device__ __forceinline__ int lds_load(const int* a) {
     return __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -990,7 +991,7 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
 #else
 #define TICK(acc) do { } while (0)
 #endif
-    for (int spins = 0;;) {
+    for (int spins = 0, seen_progress = 0;;) {
         if (uni(lds_load(ctr + FC_ABORT)) || uni(lds_load(ctr + FC_DONE)) >= n_valid) break;
         const int lh = uni(lds_load(ctr + FC_LEAF_HEAD)), leaves = uni(lds_load(ctr + FC_LEAF_TAIL)) - lh;
         const int rh = uni(lds_load(ctr + FC_READY_HEAD)), ready = uni(lds_load(ctr + FC_READY_TAIL)) - rh;
@@ -1020,6 +1021,7 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
 #ifdef AZ_EXP_TIMING
             if (g1 >= 0) ++n_pair; else ++n_single;
 #endif
+            if (lane == 0) lds_add(ctr + FC_PROGRESS, 1);
             spins = 0;
             continue;
         }
@@ -1054,6 +1056,7 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
 #ifdef AZ_EXP_TIMING
             ++n_hbatch;
 #endif
+            if (lane == 0) lds_add(ctr + FC_PROGRESS, 1);
             spins = 0;
             continue;
         }
@@ -1083,10 +1086,17 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
 #ifdef AZ_EXP_TIMING
             ++n_step; n_stepped += take;
 #endif
+            if (lane == 0) lds_add(ctr + FC_PROGRESS, 1);
             spins = 0;
             continue;
         }
         __builtin_amdgcn_s_sleep(2);
+        {
+            // idle: the watchdog counts polls during which NO wave of the workgroup finished anything (a wave may
+            // well have nothing to do for a whole launch: a workgroup with one game keeps one or two waves busy)
+            const int progress = uni(lds_load(ctr + FC_PROGRESS));
+            if (progress != seen_progress) { seen_progress = progress; spins = 0; }
+        }
         if (++spins > WATCHDOG_SPINS) {
             if (lane == 0) {
                 lds_store(ctr + FC_ABORT, 1);

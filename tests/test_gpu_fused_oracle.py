@@ -93,3 +93,27 @@ def test_fused_move_kernel_matches_the_oracle(G, S, moves, depth):
             checked += 1
         del top
     assert checked >= G * min(moves, 7) * 0.9
+
+
+@pytest.mark.gpu
+def test_long_launch_with_idle_waves_is_not_abandoned():
+    """One game per workgroup and 8 000 simulations: six or seven of a workgroup's eight waves have nothing to do
+    for the whole launch (> 100 ms).  The kernel's watchdog must count only polls during which the workgroup as a
+    whole made no progress: every simulation is done and no error bit is raised."""
+    import torch
+    from alphazero_amd import engine as E
+    from alphazero_amd.models import AlphaZeroC4
+    from alphazero_amd.net import FusedC4Net
+    G, S = 8, 8000
+    eng = E.SelfPlayEngine(E._lib.GAME_C4, G, S, exploration_depth=4, reuse_search_tree=False, seed=0, device=0)
+    torch.manual_seed(0)
+    net = FusedC4Net.from_module(AlphaZeroC4(6, 32).eval().cuda(), 'cuda')
+    bb, info = eng.begin_move()
+    p, _ = net(bb, info)
+    eng.apply_root(p)
+    eng.move_fused(net)
+    a, ne, vis, w = eng.choose_and_advance()
+    eng.drain_finished()
+    assert vis.sum(1).tolist() == [S] * G
+    assert eng.error_flags() == 0
+    eng.close()
