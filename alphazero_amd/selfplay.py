@@ -130,7 +130,8 @@ class SelfPlayWorker:
         if flags:
             raise _engine.AzError(
                 ('a game ran out of node-pool space (raise node_capacity); ' if flags & 1 else '') +
-                ('finished games were dropped, the record ring was full (collect more often)' if flags & 2 else ''))
+                ('finished games were dropped, the record ring was full (collect more often); ' if flags & 2 else '') +
+                ('a launch of the one-launch-per-move kernel was abandoned by its watchdog' if flags & 16 else ''))
 
     def collect_finished(self):
         recs = self.engine.drain_finished()
@@ -155,7 +156,8 @@ class SelfPlayWorker:
         n, flags = head.tolist()
         self.engine_flags = flags
         if flags:
-            raise _engine.AzError(f'engine error bits {flags}: 1 = node pool exhausted, 2 = finished games dropped')
+            raise _engine.AzError(f'engine error bits {flags}: 1 = node pool exhausted, 2 = finished games dropped, '
+                                  '16 = a one-launch move was abandoned by its watchdog')
         self.games_finished += n
         return recs[:n].clone()
 

@@ -24,9 +24,12 @@ from .training import TrainingWorker
 
 def synchronous_play_and_train(config, device, num_games=1024, num_steps=None, moves_per_step=1, logdir=None,
                                summary_writer=None, seed=0, trainer_rank=0, window_states=64 * 1024, log=None,
-                               data_parallel=False):
+                               data_parallel=False, pipelined=False):
     """Runs until the model version reaches `num_steps` (default: config.training['num_steps']).
-    Returns (model_server, selfplay_worker, training_worker or None)."""
+    Returns (model_server, selfplay_worker, training_worker or None).
+    pipelined (one process only): the training step is queued on the device behind the move's kernels BEFORE the host
+    waits for that move's finished games, so the device never idles between the two (an idle device drops its
+    clocks and a 1.5 ms step then takes 5-10 ms); the step trains on the window as it was one move earlier."""
     multi = dist.is_available() and dist.is_initialized()
     rank = dist.get_rank() if multi else 0
     world = dist.get_world_size() if multi else 1
@@ -71,9 +74,12 @@ def synchronous_play_and_train(config, device, num_games=1024, num_steps=None, m
                 raise RuntimeError(f'engine error bits {flags} on some rank')
             if trainer is not None:
                 window.add_records_device(recs)
+        elif pipelined:
+            version = trainer.process_batch() or version
+            window.add_records_device(worker.collect_finished_device())
         else:
             window.add_records_device(worker.collect_finished_device())
-        if trainer is not None:
+        if trainer is not None and not (pipelined and not multi):
             version = trainer.process_batch() or version          # 0 while the window is still too small
             if log and rank == trainer_rank:
                 log(f'version {version}: {len(window)} states in the window, {window.num_games} games')

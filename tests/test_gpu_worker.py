@@ -188,9 +188,11 @@ def test_training_step_from_the_device_window():
     assert all(torch.isfinite(p).all() for p in tw.model.parameters())
 
 
-def test_synchronous_play_and_train_loop():
+@pytest.mark.parametrize('pipelined', [False, True])
+def test_synchronous_play_and_train_loop(pipelined):
     """alphazero/train.py:85-95 on one GPU: uniform self-play until the window fills, then SGD steps whose
-    weights the self-play side picks up (the fused kernel is repacked from them)."""
+    weights the self-play side picks up (the fused kernel is repacked from them); also with the training step
+    queued behind the move before the host waits for the move's records."""
     from alphazero_amd.train import synchronous_play_and_train
     cfg = _config({'module': 'alphazero.games.connectfour', 'name': 'ConnectFour'},
                   {'module': 'alphazero.games.connectfour', 'name': 'AlphaZeroC4',
@@ -199,7 +201,7 @@ def test_synchronous_play_and_train_loop():
     cfg._conf['training'] = {'lr': 0.02, 'momentum': 0.9, 'weight_decay': 1e-4, 'lr_schedule': [100],
                              'lr_schedule_gamma': 0.1, 'batch_size': 128, 'num_steps': 4}
     torch.manual_seed(0)
-    server, worker, trainer = synchronous_play_and_train(cfg, 'cuda', num_games=128, moves_per_step=4)
+    server, worker, trainer = synchronous_play_and_train(cfg, 'cuda', num_games=128, moves_per_step=4, pipelined=pipelined)
     assert server.latest(worker._model) == 4 and worker._version >= 3
     assert worker.engine.stats()['errors'] == 0 and worker.games_finished > 0
     for a, b in zip(worker._model.state_dict().values(), trainer.model.state_dict().values()):
