@@ -149,7 +149,7 @@ def test_cache_bad_size_rejected():
     eng.close()
 
 
-@pytest.mark.parametrize('G,S', [(512, 48), (8192, 24), (100, 33), (8, 20), (257, 12), (1, 40), (4000, 7)])
+@pytest.mark.parametrize('G,S', [(512, 48), (8192, 24), (100, 33), (8, 20), (257, 12), (1, 40), (4000, 7), (16384, 5)])
 def test_fused_move_equals_the_stepwise_loop(G, S):
     """az_c4_move_fused (a workgroup owns its games for the whole move, search and network in one launch)
     against the stepwise loop with az_c4net_bf16_forward: identical moves, visit counts, records, counters."""
