@@ -1450,8 +1450,8 @@ static inline dim3 group_grid(int G, int gs) {
 
 // ---------------------------------------------------------------------------
 // Scratch of az_c4_move_fused_static: the four per-game staging arrays that az_c4_move_fused takes from its
-// caller (leaf positions, leaf words, priors, values passed between the search and network phases of a
-// workgroup), for up to FUSED_STATIC_MAX_GAMES games, in device memory that belongs to the library image --
+// caller (leaf positions, leaf words, priors, values passed between a workgroup's search steps and network
+// tasks), for up to FUSED_STATIC_MAX_GAMES games, in device memory that belongs to the library image --
 // nothing is allocated to use it.  Each GPU holds its own copy at its own address; host code only ever uses
 // the per-device address looked up once in az_engine_create (the array's name is not a device pointer on the
 // host side).
@@ -1701,7 +1701,9 @@ int az_sim_step(az_engine* e, float* p, float* v, uint64_t* leaf_bb, int32_t* le
 }
 
 #ifdef AZ_EXP_TIMING
-// out: 4 phase counters of k_c4_move_fused, then the 8 counters of the network phase (az_net_dev.h)
+// out: the waves' cycles in network tasks / search steps / idle and the number of waves (k_c4_move_fused), then
+// eight more counters of that kernel: two-board tasks, one-board tasks, search steps, games stepped, the slowest
+// wave's cycles, cycles in head batches, cycles in hand-overs, head batches
 int az_debug_counters(az_engine* e, unsigned long long* out12) {
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out12, e->d.ring_count + 16, 32, hipMemcpyDeviceToHost));
