@@ -915,6 +915,9 @@ __device__ __forceinline__ bool ring_claim(int* head, int h, int n, int lane) {
     return uni(won) != 0;
 }
 
+#ifdef AZ_EXP_TIMING
+__device__ unsigned long long g_done_dbg[8];     // cycles from the start until 1 / 50 % / 75 % / 90 % / all games of a workgroup are done
+#endif
 __global__ void __launch_bounds__(NTHREADS, 2)
 k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, int32_t* leaf_info, float* p,
                 float* v, int num_sims, int gpw) {
@@ -965,6 +968,9 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
     const float* sbias = reinterpret_cast<const float*>(scr + S_BIAS);
     const int sub = lane & (GS - 1);
 
+#ifdef AZ_EXP_TIMING
+    const long long t_start = clock64();
+#endif
     // one search step of game gl by this lane's group of eight
     auto step = [&](int gl, auto tag_expand, bool sel) {
         const int g = gmap[gl];
@@ -975,7 +981,19 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (sub == 0) {
             if (!sel || num_sims <= 0) {                       // (no simulations asked for: the first select is all)
+#ifdef AZ_EXP_TIMING
+                {
+                    const int d = lds_add(ctr + FC_DONE, 1) + 1, nv = ctr[FC_GAMES];
+                    const long long now = clock64() - t_start;
+                    if (d == (nv + 1) / 2) atomicAdd(&g_done_dbg[0], (unsigned long long)now);
+                    if (d == (3 * nv + 3) / 4) atomicAdd(&g_done_dbg[1], (unsigned long long)now);
+                    if (d == (9 * nv + 9) / 10) atomicAdd(&g_done_dbg[2], (unsigned long long)now);
+                    if (d == nv) { atomicAdd(&g_done_dbg[3], (unsigned long long)now); atomicAdd(&g_done_dbg[4], 1ull); }
+                    if (d == 1) atomicAdd(&g_done_dbg[5], (unsigned long long)now);
+                }
+#else
                 lds_add(ctr + FC_DONE, 1);
+#endif
             } else {
                 nsel[gl] += 1;
                 if (kind == AZ_LEAF_EVAL || kind == AZ_LEAF_ROOT) ring_push(leafq, ctr + FC_LEAF_TAIL, gl);
@@ -1701,6 +1719,13 @@ int az_sim_step(az_engine* e, float* p, float* v, uint64_t* leaf_bb, int32_t* le
 }
 
 #ifdef AZ_EXP_TIMING
+int az_debug_done(unsigned long long* out8) {
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_done_dbg), 64));
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_done_dbg), z, 64));
+    return 0;
+}
 // out: the waves' cycles in network tasks / search steps / idle and the number of waves (k_c4_move_fused), then
 // eight more counters of that kernel: two-board tasks, one-board tasks, search steps, games stepped, the slowest
 // wave's cycles, cycles in head batches, cycles in hand-overs, head batches

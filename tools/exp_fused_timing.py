@@ -34,3 +34,11 @@ for i in range(12):
           f'towers {out[0] / n / tot:.1%} heads {d[5] / n / tot:.1%} hand-over {d[6] / n / tot:.1%} search {out[1] / n / tot:.1%} idle {out[2] / n / tot:.1%}')
     print(f'   tasks: {d[0]} pairs ({out[0] / max(d[0] + d[1], 1):.0f} + {d[5] / max(d[0] + d[1], 1):.0f} cycles per task incl. singles), {d[1]} singles; '
           f'head batches {d[7]} with {(2 * d[0] + d[1]) / max(d[7], 1):.1f} boards each, {d[5] / max(d[7], 1):.0f} cycles per batch; search steps {d[2]} with {d[3] / max(d[2], 1):.2f} games each, {out[1] / max(d[2], 1):.0f} cycles per step')
+
+dd = (C.c_ulonglong * 8)()
+if hasattr(eng.lib, 'az_debug_done'):
+    eng.lib.az_debug_done.argtypes = [C.c_void_p]
+    eng.lib.az_debug_done(dd)
+    n = max(dd[4], 1)
+    print('cycles from the start of a workgroup until its first game / 50 % / 75 % / 90 % / all of its games are done '
+          f'(mean over workgroups and moves): {dd[5] / n:.0f} / {dd[0] / n:.0f} / {dd[1] / n:.0f} / {dd[2] / n:.0f} / {dd[3] / n:.0f}')
