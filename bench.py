@@ -273,6 +273,45 @@ def config4_leaf_eval(dev, iters=10, n=16384):
             'flops_per_leaf': trunk_flops_per_leaf(10, 128), 'dtype': 'bf16 MFMA, f32 accumulate'}
 
 
+def config2_selfplay(dev, fused, games=1024, sims=200, steps=12):
+    """BASELINE config 2: 1 024 concurrent Connect Four games, 200 simulations per move, on one GPU; the same path
+    as the headline line (one az_c4_move_fused launch per move, four games per compute unit here)."""
+    import torch
+    from alphazero_amd import engine as E
+    eng = E.SelfPlayEngine(E._lib.GAME_C4, games, sims, exploration_depth=4, reuse_search_tree=True,
+                           alpha=0.3, epsilon=0.25, seed=1, device=dev.index)
+
+    def step():
+        bb, info = eng.begin_move()
+        p, _ = fused(bb, info)
+        eng.apply_root(p)
+        eng.move_fused(fused)
+        eng.choose_and_advance()
+        eng.drain_finished_bytes()
+    for i in range(120):                          # spread the games' ages first (uniform prior: cheap)
+        eng.begin_move_uniform()
+        eng.run_sims_uniform(sims)
+        eng.choose_and_advance()
+        if i % 2 == 1:
+            eng.drain_finished()
+    for _ in range(10):
+        step()
+    st0 = eng.stats()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t1) / steps
+    st1 = eng.stats()
+    assert st1['sims'] - st0['sims'] == games * sims * steps and st1['errors'] == 0
+    eng.close()
+    return {'workload': f'connect4 self-play, {sims} sims/move, {games} games on one GPU, model c4_6x32',
+            'value': games / dt, 'unit': 'positions/s', 'sims_per_s': games * sims / dt, 'ms_per_step': 1e3 * dt,
+            'steps': steps, 'launches': 'one per move (az_c4_move_fused)',
+            'leaf_eval_fraction': (st1['leaf_evals'] - st0['leaf_evals']) / (games * sims * steps)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -302,7 +341,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-extras', action='store_true',
-                    help='skip the untimed extra measurements of the N = 1 line (fp32 network, agreement, 10x128 batches)')
+                    help='skip the extra measurements of the N = 1 line, made after the timed region (fp32 network, agreement, '
+                         'BASELINE configs 2, 4 and 5)')
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -597,7 +637,8 @@ def main():
                                'note': 'the configuration whose network outputs are within 1e-5 of the reference fp32 net'}
             # (b) how often the bf16 production path changes a move or a visit vector
             out['agreement'] = measure_agreement(dev, fused, f32, S)
-            # (c) BASELINE config 4
+            # (c) BASELINE configs 2 and 4
+            out['config2_selfplay'] = config2_selfplay(dev, fused)
             out['config4_leaf_eval'] = config4_leaf_eval(dev)
             # (d) BASELINE config 5 on one GPU: the training step on the device-resident replay window, alone
             # and inside the self-play loop (one SGD step and one weight hand-over per move of all games, as the
