@@ -852,7 +852,7 @@ __global__ void __launch_bounds__(1024) k_fused_balance(Dev E, int gpw, int grid
 //         in sight) in the wave's registers, head planes into the games' slots in LDS--> plane queue
 //     plane queue --one wave: the fully connected heads of ALL boards that wait, up to 32 columns of the
 //         same MFMAs--> (p, v), ready queue
-// until the expand/backup that follows its num_sims-th select.  The eight waves are identical workers: a
+// until the expand/backup that follows its num_sims-th select.  The FUSED_WAVES waves are identical workers: a
 // worker takes a network task when two leaves are queued; else the heads, if eight boards wait for them (or any,
 // when there is nothing to search) and no other wave is at it; else up to eight ready games for one search
 // step (eight lanes per tree); else it sleeps.  So the tree walks' memory latency hides behind other games'
@@ -862,6 +862,12 @@ __global__ void __launch_bounds__(1024) k_fused_balance(Dev E, int gpw, int grid
 // workgroup barrier after the set-up.  A game's own sequence select -> evaluate -> expand/backup is what it
 // is in the lock-step kernels and the network's outputs do not depend on which leaf shares a task or a head
 // batch, so trees, visit counts and records are bit-identical to the two-kernel path.
+// What bounds the kernel is the SIMDs' instruction issue: the matrix pipes are busy two thirds of the time, the
+// other vector instructions (one per MFMA in a task, some 2 400 per search step) a third, and the two overlap
+// little (an MFMA keeps the vector issue port for half of its sixteen cycles, and a SIMD serves its older wave
+// first: tools/simd_share_probe.hip).  More waves, other priorities or more head servers therefore only move
+// time between the games' queue waits and their service times; search steps and head batches run at raised
+// priority because they are short and whole batches of games wait for them.
 // Hand-offs: (p, v), slots, nodes and leaf positions are written, then a workgroup-scope release fence, then
 // the queue entry (LDS atomics); the taker reads the entry, then an acquire fence.  A queue is a ring of
 // FUSED_QUEUE words (game + 1, 0 = its writer has the slot but has not stored yet) with a head and a tail
@@ -871,16 +877,28 @@ __global__ void __launch_bounds__(1024) k_fused_balance(Dev E, int gpw, int grid
 // leaves, and bit 4 of the engine's error flags reports it.
 // ---------------------------------------------------------------------------
 #define FUSED_QUEUE 64                 // ring slots >= games per workgroup
+#ifndef FUSED_WAVES
+// worker waves per workgroup: 8 (two per SIMD) or 12 (three per SIMD: the kernel fits their 168 registers
+// without scratch; measured 2 % slower, the SIMDs have no issue slots left for a third wave)
+#define FUSED_WAVES 8
+#endif
+#define FUSED_THREADS (64 * FUSED_WAVES)
 #ifndef FUSED_HEADS_MIN
 #define FUSED_HEADS_MIN 8              // boards waiting for their heads from which a worker prefers them to a search step
 #endif
 // the games' head planes live behind the network scratch: one slot per game
 #define FX_PLANES S_BYTES
+#ifdef AZ_EXP_TIMING
+#define FX_TS (FX_PLANES + 64 * PLANE_SLOT)     // tuning build: int [64], when each game entered the queue it is in
+#define FX_END (FX_TS + 256)
+#else
 #define FX_END (FX_PLANES + 64 * PLANE_SLOT)
+#endif
 #define FUSED_LDS_BYTES (OFF_BIAS + FX_END)
 #define WATCHDOG_SPINS (1 << 20)       // x >= 128 cycles per poll: far beyond any wait of a healthy launch
 enum { FC_LEAF_HEAD = 0, FC_LEAF_TAIL, FC_DONE, FC_ABORT, FC_READY_HEAD, FC_READY_TAIL, FC_SEARCHING, FC_GAMES,
-       FC_PLANES_HEAD, FC_PLANES_TAIL, FC_HEADS_LOCK, FC_PROGRESS };
+       FC_PLANES_HEAD, FC_PLANES_TAIL, FC_HEADS_LOCK, FC_PROGRESS,
+       FC_TOWERS /* tuning build: network tasks running on each SIMD, one byte per SIMD */ };
 
 __device__ __forceinline__ int lds_load(const int* a) {
     return __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -915,10 +933,21 @@ __device__ __forceinline__ bool ring_claim(int* head, int h, int n, int lane) {
     return uni(won) != 0;
 }
 
+// A copy of the lane index that the compiler cannot see through: what a phase of the kernel computes from it (LDS
+// addresses of weights, planes, queues) is computed inside that phase instead of being kept in registers across
+// the other phases.  With it the kernel needs 177 registers instead of 233 (and fits 168 without scratch).
+__device__ __forceinline__ int phase_lane(int lane) {
+    asm volatile("" : "+v"(lane));
+    return lane;
+}
+
 #ifdef AZ_EXP_TIMING
+// 0..2 cycles games waited in the leaf / plane / ready queue, 3..5 the number of waits; 6, 7 cycles and number of the
+// two-board tasks that had their SIMD to themselves when they began and ended; 8, 9 the same for tasks that shared it
+__device__ unsigned long long g_wait_dbg[10];
 __device__ unsigned long long g_done_dbg[8];     // cycles from the start until 1 / 50 % / 75 % / 90 % / all games of a workgroup are done
 #endif
-__global__ void __launch_bounds__(NTHREADS, 2)
+__global__ void __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4)
 k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, int32_t* leaf_info, float* p,
                 float* v, int num_sims, int gpw) {
     constexpr int GS = 8;
@@ -928,7 +957,7 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     {
         uint4* z = reinterpret_cast<uint4*>(scr);
-        for (int i = tid; i < FX_END / 16; i += NTHREADS) z[i] = make_uint4(0, 0, 0, 0);
+        for (int i = tid; i < FX_END / 16; i += FUSED_THREADS) z[i] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
     if (tid < 99) reinterpret_cast<float*>(scr + S_BIAS)[tid] = reinterpret_cast<const float*>(blob + OFF_BIAS)[tid];
@@ -938,7 +967,7 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
         reinterpret_cast<float*>(scr + S_W2)[tid] = reinterpret_cast<const float*>(blob + OFF_W2)[tid];
     }
     if (tid < 64) reinterpret_cast<float*>(scr + S_BP)[tid] = reinterpret_cast<const float*>(blob + OFF_BP)[tid];
-    load_weights(blob, wlds, tid);         // once per move
+    if (tid < NTHREADS) load_weights(blob, wlds, tid);         // once per move
 
     // LDS words of the hand-offs (all zero now): the task-list area holds the games' select counts, the value
     // partial-sum area the two rings
@@ -952,7 +981,7 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
     int* ctr = reinterpret_cast<int*>(scr + S_WT);                       // FC_* words
     static_assert(8 * MAXIT * 2 >= 128 && (3 * FUSED_QUEUE + 32) * 4 <= 8 * 32 * 4, "LDS areas reused by the hand-off words");
     uint64_t* lbb = reinterpret_cast<uint64_t*>(scr + S_LBB);            // [64][2] leaf positions
-    const int wave_id = (int)blockIdx.x * (NTHREADS / 64) + wave;
+    const int wave_id = (int)blockIdx.x * FUSED_WAVES + uni(wave);         // (a scalar)
     if (wave == 0) {
         // the workgroup's games: the leading non-negative entries of its row of E.order; all start ready for
         // their first select
@@ -966,13 +995,18 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
     const int n_valid = ctr[FC_GAMES];
 
     const float* sbias = reinterpret_cast<const float*>(scr + S_BIAS);
-    const int sub = lane & (GS - 1);
-
 #ifdef AZ_EXP_TIMING
     const long long t_start = clock64();
 #endif
     // one search step of game gl by this lane's group of eight
-    auto step = [&](int gl, auto tag_expand, bool sel) {
+#ifdef AZ_EXP_TIMING
+    int* tstamp = reinterpret_cast<int*>(scr + FX_TS);
+    if (wave == 0) tstamp[lane] = (int)clock64();
+    long long w_leaf = 0, w_plane = 0, w_ready = 0, n_leaf = 0, n_plane = 0, n_ready = 0;
+    const int simd_shift = 8 * (int)__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11));      // HW_ID bits 5:4
+#endif
+    auto step = [&](int lane, int gl, auto tag_expand, bool sel) {
+        const int sub = lane & (GS - 1);
         const int g = gmap[gl];
         Slot* s = E.slots + g;
         uint4* pool = E.pool + (size_t)g * E.cap * (GameC4::A + 1);
@@ -996,6 +1030,9 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
 #endif
             } else {
                 nsel[gl] += 1;
+#ifdef AZ_EXP_TIMING
+                tstamp[gl] = (int)clock64();
+#endif
                 if (kind == AZ_LEAF_EVAL || kind == AZ_LEAF_ROOT) ring_push(leafq, ctr + FC_LEAF_TAIL, gl);
                 else ring_push(readyq, ctr + FC_READY_TAIL, gl);     // terminal (backed up already) or cached
             }
@@ -1022,15 +1059,34 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
             TICK(t_idle);
             const int g0 = ring_take(leafq, lh, lane), g1 = take == 2 ? ring_take(leafq, lh + 1, lane) : -1;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#ifdef AZ_EXP_TIMING
+            if (lane == 0) {
+                const int now = (int)clock64();
+                w_leaf += (unsigned)(now - tstamp[g0]); ++n_leaf;
+                if (g1 >= 0) { w_leaf += (unsigned)(now - tstamp[g1]); ++n_leaf; }
+            }
+            const int towers_before = (uni(lane == 0 ? lds_add(ctr + FC_TOWERS, 1 << simd_shift) : 0) >> simd_shift) & 255;
+            const long long task_t0 = clock64();
+#endif
             __bf16* hp0 = reinterpret_cast<__bf16*>(planes + g0 * PLANE_SLOT);
+            const int tl = phase_lane(lane);
             if (g1 >= 0) {
-                const int g_mine = (lane & 8) ? g1 : g0;
+                const int g_mine = (tl & 8) ? g1 : g0;
                 __bf16* hp1 = reinterpret_cast<__bf16*>(planes + g1 * PLANE_SLOT);
-                trunk_task<ROWS>(wlds, sbias, num_blocks, lbb + 2 * g_mine, hp0, hp0 + 96, hp1, hp1 + 96, lane);
+                trunk_task<ROWS>(wlds, sbias, num_blocks, lbb + 2 * g_mine, hp0, hp0 + 96, hp1, hp1 + 96, tl);
             } else {
-                trunk_task<ROWS / 2>(wlds, sbias, num_blocks, lbb + 2 * g0, hp0, hp0 + 96, nullptr, nullptr, lane);
+                trunk_task<ROWS / 2>(wlds, sbias, num_blocks, lbb + 2 * g0, hp0, hp0 + 96, nullptr, nullptr, tl);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // the planes, before the boards are queued
+#ifdef AZ_EXP_TIMING
+            {
+                const int towers_after = ((uni(lane == 0 ? lds_add(ctr + FC_TOWERS, -(1 << simd_shift)) : 0) >> simd_shift) & 255) - 1;
+                const unsigned long long dt = (unsigned long long)(clock64() - task_t0);
+                if (lane == 0 && g1 >= 0 && towers_before == 0 && towers_after == 0) { atomicAdd(&g_wait_dbg[6], dt); atomicAdd(&g_wait_dbg[7], 1ull); }
+                if (lane == 0 && g1 >= 0 && towers_before >= 1 && towers_after >= 1) { atomicAdd(&g_wait_dbg[8], dt); atomicAdd(&g_wait_dbg[9], 1ull); }
+                if (lane == 0) { tstamp[g0] = (int)clock64(); if (g1 >= 0) tstamp[g1] = tstamp[g0]; }
+            }
+#endif
             if (lane == 0) {
                 ring_push(planeq, ctr + FC_PLANES_TAIL, g0);
                 if (g1 >= 0) ring_push(planeq, ctr + FC_PLANES_TAIL, g1);
@@ -1054,19 +1110,28 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
             n = n < 32 ? n : 32;
             TICK(t_idle);
             if (n > 0) {
-                if (lane == 0) { lds_store(ctr + FC_PLANES_HEAD, ph2 + n); lds_add(ctr + FC_SEARCHING, n); }
-                if (lane < n) {
-                    int* slot = planeq + ((ph2 + lane) & (FUSED_QUEUE - 1));
+                const int hl = phase_lane(lane);
+                if (hl == 0) { lds_store(ctr + FC_PLANES_HEAD, ph2 + n); lds_add(ctr + FC_SEARCHING, n); }
+                if (hl < n) {
+                    int* slot = planeq + ((ph2 + hl) & (FUSED_QUEUE - 1));
                     int x;
                     while ((x = lds_load(slot)) == 0) __builtin_amdgcn_s_sleep(1);      // its writer is one store behind
                     lds_store(slot, 0);
-                    batch[lane] = x - 1;
+                    batch[hl] = x - 1;
+#ifdef AZ_EXP_TIMING
+                    w_plane += (unsigned)((int)clock64() - tstamp[x - 1]); ++n_plane;
+#endif
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                heads_batch(wlds, scr, planes, batch, n, gmap, lbb, p, v, lane);
+                __builtin_amdgcn_s_setprio(3);     // a short chain of dependent steps that up to 32 games wait for
+                heads_batch(wlds, scr, planes, batch, n, gmap, lbb, p, v, hl);
+                __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // (p, v), before the games are queued
-                if (lane < n) ring_push(readyq, ctr + FC_READY_TAIL, batch[lane]);
-                if (lane == 0) lds_add(ctr + FC_SEARCHING, -n);
+#ifdef AZ_EXP_TIMING
+                if (hl < n) tstamp[batch[hl]] = (int)clock64();
+#endif
+                if (hl < n) ring_push(readyq, ctr + FC_READY_TAIL, batch[hl]);
+                if (hl == 0) lds_add(ctr + FC_SEARCHING, -n);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) lds_store(ctr + FC_HEADS_LOCK, 0);
@@ -1090,13 +1155,17 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
                 int* slot = readyq + ((rh + lane) & (FUSED_QUEUE - 1));
                 while ((mine = lds_load(slot)) == 0) __builtin_amdgcn_s_sleep(1);      // its writer is one store behind
                 lds_store(slot, 0);
+#ifdef AZ_EXP_TIMING
+                w_ready += (unsigned)((int)clock64() - tstamp[mine - 1]); ++n_ready;
+#endif
             }
             const int gl = __shfl(mine, lane >> 3) - 1;                              // -1: no game for this group
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (gl >= 0) {
                 const int done = nsel[gl];
-                if (done == 0) step(gl, std::false_type{}, true);          // the game's first select
-                else step(gl, std::true_type{}, done < num_sims);
+                const int sl = phase_lane(lane);
+                if (done == 0) step(sl, gl, std::false_type{}, true);          // the game's first select
+                else step(sl, gl, std::true_type{}, done < num_sims);
             }
             __builtin_amdgcn_s_setprio(0);
             if (lane == 0) lds_add(ctr + FC_SEARCHING, -take);             // after the pushes of this step
@@ -1125,6 +1194,9 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
     }
 #ifdef AZ_EXP_TIMING
     TICK(t_idle);
+    atomicAdd(&g_wait_dbg[0], (unsigned long long)w_leaf); atomicAdd(&g_wait_dbg[1], (unsigned long long)w_plane);
+    atomicAdd(&g_wait_dbg[2], (unsigned long long)w_ready); atomicAdd(&g_wait_dbg[3], (unsigned long long)n_leaf);
+    atomicAdd(&g_wait_dbg[4], (unsigned long long)n_plane); atomicAdd(&g_wait_dbg[5], (unsigned long long)n_ready);
     if (lane == 0) {
         unsigned long long* dbg = reinterpret_cast<unsigned long long*>(E.ring_count + 16);
         atomicAdd(dbg + 0, (unsigned long long)t_task);
@@ -1609,9 +1681,9 @@ int az_set_model_version(az_engine* e, int32_t version) {
     return 0;
 }
 
-// hit counters: one per wavefront of any search grid (G / 8 trees per wave at least, 8 waves per
+// hit counters: one per wavefront of any search grid (G / 8 trees per wave at least, at most 16 waves per
 // workgroup of the one-launch-per-move kernel, whose grid never exceeds G workgroups)
-static size_t cache_counters(int G) { return (size_t)8 * G + 8; }
+static size_t cache_counters(int G) { return (size_t)16 * G + 16; }
 
 int az_eval_cache_enable(az_engine* e, int32_t log2_entries) {
     if (!e) return az_fail("null engine");
@@ -1719,6 +1791,13 @@ int az_sim_step(az_engine* e, float* p, float* v, uint64_t* leaf_bb, int32_t* le
 }
 
 #ifdef AZ_EXP_TIMING
+int az_debug_waits(unsigned long long* out10) {
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out10, HIP_SYMBOL(g_wait_dbg), 80));
+    unsigned long long z[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_wait_dbg), z, 80));
+    return 0;
+}
 int az_debug_done(unsigned long long* out8) {
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_done_dbg), 64));
@@ -1741,7 +1820,7 @@ int az_debug_counters(az_engine* e, unsigned long long* out12) {
 #endif
 
 // games per workgroup of the one-launch-per-move kernel: spread over one workgroup per compute unit, at most
-// 64 (eight search lanes per game, 512 threads)
+// 64 (eight search lanes per game)
 #define FUSED_MAX_GPW 64
 static int fused_launch(az_engine* e, const uint8_t* blob, int32_t num_blocks, uint64_t* leaf_bb, int32_t* leaf_info,
                         float* p, float* v, hipStream_t st) {
@@ -1755,7 +1834,7 @@ static int fused_launch(az_engine* e, const uint8_t* blob, int32_t num_blocks, u
     if (int rc = az_set_kernel_lds(reinterpret_cast<const void*>(k_c4_move_fused), FUSED_LDS_BYTES, g_fused_attr_done)) return rc;
     if (e->d.G > BALANCE_MAX_GAMES) return az_fail("az_c4_move_fused: more than 16384 games");
     hipLaunchKernelGGL(k_fused_balance, dim3(1), dim3(1024), 0, st, e->d, gpw, grid);
-    hipLaunchKernelGGL(k_c4_move_fused, dim3(grid), dim3(NTHREADS), FUSED_LDS_BYTES, st, e->d, blob, (int)num_blocks, leaf_bb,
+    hipLaunchKernelGGL(k_c4_move_fused, dim3(grid), dim3(FUSED_THREADS), FUSED_LDS_BYTES, st, e->d, blob, (int)num_blocks, leaf_bb,
                        leaf_info, p, v, (int)e->d.S, gpw);
     AZ_LAUNCH_CHECK("k_c4_move_fused");
     return 0;

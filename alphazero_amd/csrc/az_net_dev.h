@@ -375,41 +375,39 @@ __device__ __forceinline__ void heads_batch(const uint8_t* wlds, uint8_t* scr, c
     bf16x8 bv[3];
 #pragma unroll
     for (int s = 0; s < 3; ++s) bv[s] = *reinterpret_cast<const bf16x8*>(chv + 16 * s + 8 * hh);
-    // four row tiles at a time: their MFMA chains are independent and hide each other's latency
+    // two row tiles at a time: their MFMA chains are independent and hide each other's latency (four at a time are
+    // no faster and cost 56 registers more)
 #pragma unroll 1
-    for (int h4 = 0; h4 < 8; h4 += 4) {
-        bf16x8 wf[4][3];
+    for (int h2 = 0; h2 < 8; h2 += 2) {
+        bf16x8 wf[2][3];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int s = 0; s < 3; ++s) wf[t][s] = frag_ptr(wlds, OFF_F1 + ((h4 + t) * 3 + s) * 1024, lane)[0];
-        f32x4 b1v[2][4], w2v[2][4];                            // biases / second-layer weights of tile t (slot t & 1)
-        auto load_bw = [&](int t) {
+            for (int s = 0; s < 3; ++s) wf[t][s] = frag_ptr(wlds, OFF_F1 + ((h2 + t) * 3 + s) * 1024, lane)[0];
+        f32x4 b1v[2][4], w2v[2][4];                            // biases / second-layer weights of tile t
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                b1v[t & 1][g] = *reinterpret_cast<const f32x4*>(sb1 + 32 * (h4 + t) + 8 * g + 4 * hh);
-                w2v[t & 1][g] = *reinterpret_cast<const f32x4*>(sw2 + 32 * (h4 + t) + 8 * g + 4 * hh);
+                b1v[t][g] = *reinterpret_cast<const f32x4*>(sb1 + 32 * (h2 + t) + 8 * g + 4 * hh);
+                w2v[t][g] = *reinterpret_cast<const f32x4*>(sw2 + 32 * (h2 + t) + 8 * g + 4 * hh);
             }
-        };
-        load_bw(0);
         HEADS_FENCE();
-        f32x16 acc[4];
+        f32x16 acc[2];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
 #pragma unroll
         for (int s = 0; s < 3; ++s)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = MFMA(wf[t][s], bv[s], acc[t]);
+            for (int t = 0; t < 2; ++t) acc[t] = MFMA(wf[t][s], bv[s], acc[t]);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            if (t + 1 < 4) load_bw(t + 1);
-            HEADS_FENCE();
+        for (int t = 0; t < 2; ++t) {
             float part = 0.0f;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 b1 = b1v[t & 1][g], wv = w2v[t & 1][g];
+                const f32x4 b1 = b1v[t][g], wv = w2v[t][g];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) part = fmaf(fmaxf(acc[t][4 * g + i] + b1[i], 0.0f), wv[i], part);
             }
@@ -418,38 +416,33 @@ __device__ __forceinline__ void heads_batch(const uint8_t* wlds, uint8_t* scr, c
         }
     }
     {
-        bf16x8 pf[2][6], bp8[6];
-        f32x4 bpv[2][4];
+        // the policy FC, one row tile (cells 0..31 / 32..41) after the other
+        bf16x8 bp8[6];
 #pragma unroll
-        for (int s = 0; s < 6; ++s) {
-            bp8[s] = *reinterpret_cast<const bf16x8*>(chp + 16 * s + 8 * hh);
+        for (int s = 0; s < 6; ++s) bp8[s] = *reinterpret_cast<const bf16x8*>(chp + 16 * s + 8 * hh);
+#pragma unroll 1
+        for (int hn = 0; hn < 2; ++hn) {
+            bf16x8 pf[6];
+            f32x4 bpv[4];
 #pragma unroll
-            for (int hn = 0; hn < 2; ++hn) pf[hn][s] = frag_ptr(wlds, OFF_PF + (hn * 6 + s) * 1024, lane)[0];
-        }
+            for (int s = 0; s < 6; ++s) pf[s] = frag_ptr(wlds, OFF_PF + (hn * 6 + s) * 1024, lane)[0];
 #pragma unroll
-        for (int hn = 0; hn < 2; ++hn)
+            for (int g = 0; g < 4; ++g) bpv[g] = *reinterpret_cast<const f32x4*>(sbp + 32 * hn + 8 * g + 4 * hh);
+            HEADS_FENCE();
+            f32x16 pacc;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) bpv[hn][g] = *reinterpret_cast<const f32x4*>(sbp + 32 * hn + 8 * g + 4 * hh);
-        HEADS_FENCE();
-        f32x16 pacc[2];
+            for (int i = 0; i < 16; ++i) pacc[i] = 0.0f;
 #pragma unroll
-        for (int hn = 0; hn < 2; ++hn)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) pacc[hn][i] = 0.0f;
-#pragma unroll
-        for (int s = 0; s < 6; ++s)
-#pragma unroll
-            for (int hn = 0; hn < 2; ++hn) pacc[hn] = MFMA(pf[hn][s], bp8[s], pacc[hn]);
-        if (c < n) {
-#pragma unroll
-            for (int hn = 0; hn < 2; ++hn)
+            for (int s = 0; s < 6; ++s) pacc = MFMA(pf[s], bp8[s], pacc);
+            if (c < n) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 o4;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) o4[i] = pacc[hn][4 * g + i] + bpv[hn][g][i];
+                    for (int i = 0; i < 4; ++i) o4[i] = pacc[4 * g + i] + bpv[g][i];
                     *reinterpret_cast<f32x4*>(lg + c * 64 + 32 * hn + 8 * g + 4 * hh) = o4;
                 }
+            }
         }
     }
 #undef HEADS_FENCE

@@ -35,6 +35,15 @@ for i in range(12):
     print(f'   tasks: {d[0]} pairs ({out[0] / max(d[0] + d[1], 1):.0f} + {d[5] / max(d[0] + d[1], 1):.0f} cycles per task incl. singles), {d[1]} singles; '
           f'head batches {d[7]} with {(2 * d[0] + d[1]) / max(d[7], 1):.1f} boards each, {d[5] / max(d[7], 1):.0f} cycles per batch; search steps {d[2]} with {d[3] / max(d[2], 1):.2f} games each, {out[1] / max(d[2], 1):.0f} cycles per step')
 
+ww = (C.c_ulonglong * 10)()
+if hasattr(eng.lib, 'az_debug_waits'):
+    eng.lib.az_debug_waits.argtypes = [C.c_void_p]
+    eng.lib.az_debug_waits(ww)
+    print('mean cycles a game waits in the leaf queue (search step done -> network task starts) / plane queue (task done -> '
+          'head batch starts) / ready queue (heads or search step done -> next search step starts): '
+          f'{ww[0] / max(ww[3], 1):.0f} / {ww[1] / max(ww[4], 1):.0f} / {ww[2] / max(ww[5], 1):.0f}  (waits counted: {ww[3]}, {ww[4]}, {ww[5]})')
+    print(f'two-board tasks with no other task on their SIMD when they began and when they ended: {ww[7]}, {ww[6] / max(ww[7], 1):.0f} cycles each; '
+          f'with another task there at both ends: {ww[9]}, {ww[8] / max(ww[9], 1):.0f} cycles each')
 dd = (C.c_ulonglong * 8)()
 if hasattr(eng.lib, 'az_debug_done'):
     eng.lib.az_debug_done.argtypes = [C.c_void_p]
