@@ -3,7 +3,11 @@
 // nothing, the same MFMA stream, polling LDS between sleeps, f64 divisions (the PUCT score), f32 VALU work,
 // a dependent chain of global loads (a tree walk), LDS permutes.  512 threads = two waves per SIMD; waves 0..3
 // stream, waves 4..7 are the partners and stop when the streaming waves are done; then the roles are swapped (the
-// SIMD issues the older wave first).
+// SIMD issues the older wave first), and the experiment is repeated with v_mfma_f32_32x32x16_bf16.
+// Measured on an MI355X: alone 17.4 cycles per MFMA; two streams 18.7 (older wave) and 33.4 (younger); a younger
+// partner of any kind costs the stream <= 3 %; an OLDER partner doing f64 divisions or an f32 chain slows it to 37-41
+// cycles per MFMA; polling, pointer chasing and LDS permutes cost nothing either way.  32x32x16: 34.1 alone, 40.1 /
+// 68.6 shared, 68-78 under an older vector-heavy partner.
 // Build: hipcc --offload-arch=gfx950 -O2 -o simd_share_probe tools/simd_share_probe.hip ; run on the GPU box.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -12,6 +16,58 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) short s16x2;
 
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+// the same with v_mfma_f32_32x32x16_bf16 (twice the work per instruction, four independent accumulators)
+template <int PARTNER, bool SWAP>
+__global__ void __launch_bounds__(512, 2) k32(long long* out, const int* chase, int iters) {
+    __shared__ int flag[64];
+    const int hw_wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = SWAP ? (hw_wave ^ 4) : hw_wave;
+    if (threadIdx.x < 64) flag[threadIdx.x] = 0;
+    __syncthreads();
+    const int simd = (int)__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11));
+    if (wave < 4 || PARTNER == 1) {
+        f32x16 acc[4];
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0.0f;
+        bf16x8 a0, b[4];
+        for (int j = 0; j < 8; ++j) a0[j] = (__bf16)(threadIdx.x * 0.001f);
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 8; ++j) b[i][j] = (__bf16)(i + j);
+        s16x2 m = {1, 2};
+        const long long t0 = clock64();
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[y]) : "v"(a0), "v"(b[y]));
+                asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(m) : "v"(y));
+                asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(m) : "v"(y));
+            }
+        }
+        const long long t1 = clock64();
+        float s = (float)m[0];
+        for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][3];
+        if (lane == 0 && wave < 4) __hip_atomic_fetch_add(&flag[0], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (blockIdx.x == 0 && lane == 0) { out[8 + 2 * hw_wave] = 3 * (t1 - t0); out[9 + 2 * hw_wave] = simd; }   // x3: 4 per iteration, the report divides by 12
+        if (s == 123.456f) out[7] = 1;
+        return;
+    }
+    if (blockIdx.x == 0 && lane == 0) { out[8 + 2 * hw_wave] = 0; out[9 + 2 * hw_wave] = simd; }
+    if (PARTNER == 0) return;
+    long long work = 0;
+    double x = 1.0 + lane, y = 3.0;
+    float f = 1.0f + lane;
+    while (uni(__hip_atomic_load(&flag[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < 4) {
+        if (PARTNER == 3) {
+            for (int i = 0; i < 8; ++i) { x = y / (x + 1.0); y = y + 1.0; }
+            work += 8;
+        } else if (PARTNER == 4) {
+            for (int i = 0; i < 64; ++i) f = f * 1.0001f + 0.5f;
+            work += 64;
+        }
+    }
+    if (x == 0.123 || f == 0.123f) out[7] = 2;
+    if (blockIdx.x == 0 && lane == 0 && hw_wave == (SWAP ? 0 : 4)) out[3] = work;
+}
 
 template <int PARTNER, bool SWAP>
 __global__ void __launch_bounds__(512, 2) k(long long* out, const int* chase, int iters) {
@@ -77,6 +133,19 @@ __global__ void __launch_bounds__(512, 2) k(long long* out, const int* chase, in
 }
 
 template <int PARTNER, bool SWAP>
+static void run32(const char* name, long long* d, const int* chase, int iters) {
+    for (int rep = 0; rep < 2; ++rep) {
+        hipMemset(d, 0, 256);
+        hipLaunchKernelGGL((k32<PARTNER, SWAP>), dim3(256), dim3(512), 0, 0, d, chase, iters);
+        hipDeviceSynchronize();
+    }
+    long long h[32]; hipMemcpy(h, d, 256, hipMemcpyDeviceToHost);
+    printf("32x32x16, %s partner %-24s:", SWAP ? "older  " : "younger", name);
+    for (int w = 0; w < 8; ++w) printf("  w%d@simd%lld %.1f", w, h[9 + 2 * w], (double)h[8 + 2 * w] / (12.0 * iters));
+    printf("  (cycles per MFMA; partner loop items %lld)\n", h[3]);
+}
+
+template <int PARTNER, bool SWAP>
 static void run(const char* name, long long* d, const int* chase, int iters) {
     for (int rep = 0; rep < 2; ++rep) {
         hipMemset(d, 0, 256);
@@ -108,5 +177,11 @@ int main() {
     run<4, true>("f32 VALU chain", d, chase, iters);
     run<5, true>("dependent global loads", d, chase, iters);
     run<6, true>("LDS permutes", d, chase, iters);
+    run32<0, false>("none (exits)", d, chase, iters);
+    run32<1, false>("the same MFMA stream", d, chase, iters);
+    run32<3, false>("f64 divisions", d, chase, iters);
+    run32<4, false>("f32 VALU chain", d, chase, iters);
+    run32<3, true>("f64 divisions", d, chase, iters);
+    run32<4, true>("f32 VALU chain", d, chase, iters);
     return 0;
 }
