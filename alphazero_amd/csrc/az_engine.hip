@@ -898,7 +898,8 @@ __global__ void __launch_bounds__(1024) k_fused_balance(Dev E, int gpw, int grid
 #define WATCHDOG_SPINS (1 << 20)       // x >= 128 cycles per poll: far beyond any wait of a healthy launch
 enum { FC_LEAF_HEAD = 0, FC_LEAF_TAIL, FC_DONE, FC_ABORT, FC_READY_HEAD, FC_READY_TAIL, FC_SEARCHING, FC_GAMES,
        FC_PLANES_HEAD, FC_PLANES_TAIL, FC_HEADS_LOCK, FC_PROGRESS,
-       FC_TOWERS /* tuning build: network tasks running on each SIMD, one byte per SIMD */ };
+       FC_TOWERS /* tuning build: network tasks running on each SIMD, one byte per SIMD */,
+       FC_BOARDS /* tuning build: boards this workgroup has put through the network */ };
 
 __device__ __forceinline__ int lds_load(const int* a) {
     return __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -945,6 +946,7 @@ __device__ __forceinline__ int phase_lane(int lane) {
 // 0..2 cycles games waited in the leaf / plane / ready queue, 3..5 the number of waits; 6, 7 cycles and number of the
 // two-board tasks that had their SIMD to themselves when they began and ended; 8, 9 the same for tasks that shared it
 __device__ unsigned long long g_wait_dbg[10];
+__device__ unsigned long long g_wg_dbg[2 * 1024];     // per workgroup of the last launch: cycles until its last game was done, boards evaluated
 __device__ unsigned long long g_done_dbg[8];     // cycles from the start until 1 / 50 % / 75 % / 90 % / all games of a workgroup are done
 #endif
 __global__ void __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4)
@@ -1066,6 +1068,7 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
                 if (g1 >= 0) { w_leaf += (unsigned)(now - tstamp[g1]); ++n_leaf; }
             }
             const int towers_before = (uni(lane == 0 ? lds_add(ctr + FC_TOWERS, 1 << simd_shift) : 0) >> simd_shift) & 255;
+            if (lane == 0) lds_add(ctr + FC_BOARDS, take);
             const long long task_t0 = clock64();
 #endif
             __bf16* hp0 = reinterpret_cast<__bf16*>(planes + g0 * PLANE_SLOT);
@@ -1194,6 +1197,10 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
     }
 #ifdef AZ_EXP_TIMING
     TICK(t_idle);
+    if (tid == 0 && blockIdx.x < 1024) {
+        g_wg_dbg[2 * blockIdx.x] = (unsigned long long)(clock64() - t_start);
+        g_wg_dbg[2 * blockIdx.x + 1] = (unsigned long long)lds_load(ctr + FC_BOARDS);
+    }
     atomicAdd(&g_wait_dbg[0], (unsigned long long)w_leaf); atomicAdd(&g_wait_dbg[1], (unsigned long long)w_plane);
     atomicAdd(&g_wait_dbg[2], (unsigned long long)w_ready); atomicAdd(&g_wait_dbg[3], (unsigned long long)n_leaf);
     atomicAdd(&g_wait_dbg[4], (unsigned long long)n_plane); atomicAdd(&g_wait_dbg[5], (unsigned long long)n_ready);
@@ -1791,6 +1798,11 @@ int az_sim_step(az_engine* e, float* p, float* v, uint64_t* leaf_bb, int32_t* le
 }
 
 #ifdef AZ_EXP_TIMING
+int az_debug_workgroups(unsigned long long* out2048) {
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out2048, HIP_SYMBOL(g_wg_dbg), sizeof(unsigned long long) * 2048));
+    return 0;
+}
 int az_debug_waits(unsigned long long* out10) {
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpyFromSymbol(out10, HIP_SYMBOL(g_wait_dbg), 80));

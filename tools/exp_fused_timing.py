@@ -19,12 +19,27 @@ for i in range(160):
     eng.begin_move_uniform(); eng.run_sims_uniform(S); eng.choose_and_advance()
     if i % 2: eng.drain_finished()
 out = (C.c_ulonglong * 12)()
+last_boards = None
 for i in range(12):
     bb, info = eng.begin_move(); p, _ = net(bb, info); eng.apply_root(p)
     eng.lib.az_debug_counters(eng.h, out)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record(); eng.move_fused(net); ev1.record(); torch.cuda.synchronize()
     ms = ev0.elapsed_time(ev1)
+    if hasattr(eng.lib, 'az_debug_workgroups') and i >= 2:
+        import numpy as np
+        wg = (C.c_ulonglong * 2048)()
+        eng.lib.az_debug_workgroups.argtypes = [C.c_void_p]
+        eng.lib.az_debug_workgroups(wg)
+        a = np.frombuffer(wg, dtype=np.uint64).reshape(1024, 2)[:256].astype(np.float64)
+        t, b = a[:, 0], a[:, 1]
+        if last_boards is not None:
+            slope, icpt = np.polyfit(b, t, 1)
+            resid = t - (slope * b + icpt)
+            print(f'   workgroups: cycles mean {t.mean():.3e} max/mean {t.max() / t.mean():.4f}; boards mean {b.mean():.0f} max/mean {b.max() / b.mean():.4f} '
+                  f'std/mean {b.std() / b.mean():.4f}; corr(cycles, boards) {np.corrcoef(t, b)[0, 1]:.3f}, {slope:.0f} cycles per board, '
+                  f'residual std/mean {resid.std() / t.mean():.4f} max/mean {resid.max() / t.mean():.4f}')
+        last_boards = b
     eng.choose_and_advance(); eng.drain_finished()
     eng.lib.az_debug_counters(eng.h, out)
     n = out[3]
