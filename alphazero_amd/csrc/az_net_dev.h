@@ -354,16 +354,15 @@ __device__ __forceinline__ void trunk_task(const uint8_t* wlds, const float* sbi
 //   planes  LDS, one slot of PLANE_SLOT bytes per game: 96 bf16 policy planes (k = ch*42 + cell, 84 used) then
 //           48 bf16 value plane (42 used); the padding stays zero
 //   batch   LDS int[32]: local game index of column c < n;  gmap: LDS, leaf index (row of p_out / v_out) of a
-//           local game;  lbb: LDS, the games' leaf positions.  The logits pass through scr + S_LG.
+//           local game;  lbb: LDS, the games' leaf positions.  The logits pass through lg (LDS, float [n boards][64]).
 #define PLANE_SLOT 288
-__device__ __forceinline__ void heads_batch(const uint8_t* wlds, uint8_t* scr, const uint8_t* planes, const int* batch,
+__device__ __forceinline__ void heads_batch(const uint8_t* wlds, uint8_t* scr, float* lg, const uint8_t* planes, const int* batch,
                                             int n, const int* gmap, const uint64_t* lbb, float* p_out, float* v_out,
                                             int lane) {
     const float* sbias = reinterpret_cast<const float*>(scr + S_BIAS);
     const float* sb1 = reinterpret_cast<const float*>(scr + S_B1);
     const float* sw2 = reinterpret_cast<const float*>(scr + S_W2);
     const float* sbp = reinterpret_cast<const float*>(scr + S_BP);
-    float* lg = reinterpret_cast<float*>(scr + S_LG);          // [32 boards][64]
     const int hh = lane >> 5, c = lane & 31;
     const int my_game = batch[c < n ? c : 0];                  // (columns past n repeat column 0)
     const __bf16* chp = reinterpret_cast<const __bf16*>(planes + my_game * PLANE_SLOT);
