@@ -611,103 +611,113 @@ def main():
         if not multi and fused_move and not args.no_extras:
             from alphazero_amd.net import FusedC4NetF32
             f32 = FusedC4NetF32(net, dev)
-            # (a) the same self-play loop with the fp32 parity kernel evaluating every leaf (stepwise calls)
-            def f32_step():
-                bb, info = eng.begin_move()
-                p, _ = f32(bb, info)
-                eng.apply_root(p)
-                bb, info = eng.select()
-                for s_ in range(S):
-                    p, v = f32(bb, info)
-                    if s_ < S - 1:
-                        bb, info = eng.sim_step(p, v)
-                    else:
-                        eng.expand_backup(p, v)
-                eng.choose_and_advance()
-                eng.drain_finished_bytes()
-            f32_step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(2):
+            def extra(name, fn):
+                # a failure in an extra measurement must not cost the line its headline figures
+                try:
+                    out[name] = fn()
+                except Exception as e:                  # noqa: BLE001
+                    out[name] = {'error': f'{type(e).__name__}: {e}'}
+            def extra_fp32():
+                # (a) the same self-play loop with the fp32 parity kernel evaluating every leaf (stepwise calls)
+                def f32_step():
+                    bb, info = eng.begin_move()
+                    p, _ = f32(bb, info)
+                    eng.apply_root(p)
+                    bb, info = eng.select()
+                    for s_ in range(S):
+                        p, v = f32(bb, info)
+                        if s_ < S - 1:
+                            bb, info = eng.sim_step(p, v)
+                        else:
+                            eng.expand_backup(p, v)
+                    eng.choose_and_advance()
+                    eng.drain_finished_bytes()
                 f32_step()
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t1) / 2
-            out['fp32_net'] = {'value': G / dt, 'unit': 'positions/s', 'ms_per_step': 1e3 * dt, 'steps': 2,
-                               'kernel': 'k_c4net_f32 (v_mfma_f32_32x32x2_f32, every leaf) + k_sim_step_p per simulation',
-                               'note': 'the configuration whose network outputs are within 1e-5 of the reference fp32 net'}
-            # (b) how often the bf16 production path changes a move or a visit vector
-            out['agreement'] = measure_agreement(dev, fused, f32, S)
-            # (c) BASELINE configs 2 and 4
-            out['config2_selfplay'] = config2_selfplay(dev, fused)
-            out['config4_leaf_eval'] = config4_leaf_eval(dev)
-            # (d) BASELINE config 5 on one GPU: the training step on the device-resident replay window, alone
-            # and inside the self-play loop (one SGD step and one weight hand-over per move of all games, as the
-            # reference's synchronous mode alternates them, alphazero/train.py:86-96)
-            from alphazero_amd.config import AlphaZeroConfig
-            from alphazero_amd.games import ConnectFour
-            from alphazero_amd.replay_buffer import DeviceReplayWindow
-            from alphazero_amd.training import TrainingWorker
-            tcfg = AlphaZeroConfig(conf={
-                'game': {'module': 'alphazero.games.connectfour', 'name': 'ConnectFour'},
-                'model': {'module': 'alphazero.games.connectfour', 'name': 'AlphaZeroC4',
-                          'kwargs': {'num_blocks': blocks, 'channels_per_block': ch}},
-                'loss': {'module': 'alphazero.loss', 'name': 'AlphaZeroLoss'},
-                'training': {'num_steps': 10000, 'batch_size': 128, 'lr': 0.2, 'momentum': 0.9, 'weight_decay': 1e-4,
-                             'lr_schedule_gamma': 0.1, 'lr_schedule': [1000, 2000, 4000]}})   # config/connectfour.yaml:13-20
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    f32_step()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t1) / 2
+                return {'value': G / dt, 'unit': 'positions/s', 'ms_per_step': 1e3 * dt, 'steps': 2,
+                                   'kernel': 'k_c4net_f32 (v_mfma_f32_32x32x2_f32, every leaf) + k_sim_step_p per simulation',
+                                   'note': 'the configuration whose network outputs are within 1e-5 of the reference fp32 net'}
+            def extra_config5():
+                # (d) BASELINE config 5 on one GPU: the training step on the device-resident replay window, alone
+                # and inside the self-play loop (one SGD step and one weight hand-over per move of all games, as the
+                # reference's synchronous mode alternates them, alphazero/train.py:86-96)
+                from alphazero_amd.config import AlphaZeroConfig
+                from alphazero_amd.games import ConnectFour
+                from alphazero_amd.replay_buffer import DeviceReplayWindow
+                from alphazero_amd.training import TrainingWorker
+                tcfg = AlphaZeroConfig(conf={
+                    'game': {'module': 'alphazero.games.connectfour', 'name': 'ConnectFour'},
+                    'model': {'module': 'alphazero.games.connectfour', 'name': 'AlphaZeroC4',
+                              'kwargs': {'num_blocks': blocks, 'channels_per_block': ch}},
+                    'loss': {'module': 'alphazero.loss', 'name': 'AlphaZeroLoss'},
+                    'training': {'num_steps': 10000, 'batch_size': 128, 'lr': 0.2, 'momentum': 0.9, 'weight_decay': 1e-4,
+                                 'lr_schedule_gamma': 0.1, 'lr_schedule': [1000, 2000, 4000]}})   # config/connectfour.yaml:13-20
 
-            class _Publish:
-                def update(self, model, version):
-                    self.version = version
-            window = DeviceReplayWindow(ConnectFour, 64 * 1024, dev)
-            stepwise_now[0] = False
+                class _Publish:
+                    def update(self, model, version):
+                        self.version = version
+                window = DeviceReplayWindow(ConnectFour, 64 * 1024, dev)
+                stepwise_now[0] = False
 
-            def play_and_collect():
-                one_step(False)
-                recs, head = eng.take_finished_device()
-                n_rec, flags = head.tolist()
-                assert flags == 0
-                window.add_records_device(recs[:n_rec])
-            while len(window) < 8 * 128:
+                def play_and_collect():
+                    one_step(False)
+                    recs, head = eng.take_finished_device()
+                    n_rec, flags = head.tolist()
+                    assert flags == 0
+                    window.add_records_device(recs[:n_rec])
+                while len(window) < 8 * 128:
+                    play_and_collect()
+                torch.manual_seed(0)
+                tw = TrainingWorker(tcfg, _Publish(), window, None, dev)
+                for _ in range(3):
+                    tw.process_batch()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(20):
+                    tw.process_batch()
+                torch.cuda.synchronize()
+                train_ms = 1e3 * (time.perf_counter() - t1) / 20
                 play_and_collect()
-            torch.manual_seed(0)
-            tw = TrainingWorker(tcfg, _Publish(), window, None, dev)
-            for _ in range(3):
-                tw.process_batch()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(20):
-                tw.process_batch()
-            torch.cuda.synchronize()
-            train_ms = 1e3 * (time.perf_counter() - t1) / 20
-            play_and_collect()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            loop_steps = 4
-            for _ in range(loop_steps):
-                # the SGD step and the re-pack are queued behind the move before the host waits for the move's
-                # records, so the device goes from one to the other without idling (an idle device drops its clocks
-                # and the 1.5 ms step then takes 5-10 ms: tools/train_loop_probe.py); the step therefore trains on the
-                # window as it was one move earlier
-                one_step(False)
-                v_new = tw.process_batch()
-                fused.load_module(tw.model)                  # the new weights reach the self-play kernels
-                eng.set_model_version(v_new)
-                recs, head = eng.take_finished_device()
-                n_rec, flags = head.tolist()
-                assert flags == 0
-                window.add_records_device(recs[:n_rec])
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t1) / loop_steps
-            out['config5_train_loop'] = {
-                'training_step_ms': train_ms, 'batch_size': 128, 'samples_per_s': 128 / (train_ms * 1e-3),
-                'step': 'sample from the device window + forward + az_loss_fwd_bwd + backward + az_sgd_momentum + publish; '
-                        'forward .. update replayed as one recorded HIP graph',
-                'selfplay_with_training': {'value': G / dt, 'unit': 'positions/s', 'ms_per_step': 1e3 * dt,
-                                           'steps': loop_steps,
-                                           'per_step': 'one move of every game (records stay on the device) + one SGD step + '
-                                                       're-pack of the weights for the self-play kernels'},
-                'window_states': len(window), 'note': 'one GPU; with N ranks the records are gathered on the trainer rank '
-                                                      'and the packed weights broadcast (see config.exchange)'}
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                loop_steps = 4
+                for _ in range(loop_steps):
+                    # the SGD step and the re-pack are queued behind the move before the host waits for the move's
+                    # records, so the device goes from one to the other without idling (an idle device drops its clocks
+                    # and the 1.5 ms step then takes 5-10 ms: tools/train_loop_probe.py); the step therefore trains on the
+                    # window as it was one move earlier
+                    one_step(False)
+                    v_new = tw.process_batch()
+                    fused.load_module(tw.model)                  # the new weights reach the self-play kernels
+                    eng.set_model_version(v_new)
+                    recs, head = eng.take_finished_device()
+                    n_rec, flags = head.tolist()
+                    assert flags == 0
+                    window.add_records_device(recs[:n_rec])
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t1) / loop_steps
+                return {
+                    'training_step_ms': train_ms, 'batch_size': 128, 'samples_per_s': 128 / (train_ms * 1e-3),
+                    'step': 'sample from the device window + forward + az_loss_fwd_bwd + backward + az_sgd_momentum + publish; '
+                            'forward .. update replayed as one recorded HIP graph',
+                    'selfplay_with_training': {'value': G / dt, 'unit': 'positions/s', 'ms_per_step': 1e3 * dt,
+                                               'steps': loop_steps,
+                                               'per_step': 'one move of every game (records stay on the device) + one SGD step + '
+                                                           're-pack of the weights for the self-play kernels'},
+                    'window_states': len(window), 'note': 'one GPU; with N ranks the records are gathered on the trainer rank '
+                                                          'and the packed weights broadcast (see config.exchange)'}
+            extra('fp32_net', extra_fp32)
+            # (b) how often the bf16 production path changes a move or a visit vector
+            extra('agreement', lambda: measure_agreement(dev, fused, f32, S))
+            # (c) BASELINE configs 2 and 4
+            extra('config2_selfplay', lambda: config2_selfplay(dev, fused))
+            extra('config4_leaf_eval', lambda: config4_leaf_eval(dev))
+            extra('config5_train_loop', extra_config5)
         if not args.no_cpu_baseline and not multi:      # the host-CPU baseline is timed at N = 1 only
             logical, physical = physical_cores()
             workers = cpu_share()
