@@ -721,7 +721,14 @@ def main():
         if not args.no_cpu_baseline and not multi:      # the host-CPU baseline is timed at N = 1 only
             logical, physical = physical_cores()
             workers = cpu_share()
-            pps, sps, npos, wall = cpu_baseline(args.model, S, args.cpu_seconds, workers)
+            try:
+                pps, sps, npos, wall = cpu_baseline(args.model, S, args.cpu_seconds, workers)
+            except Exception as e:                      # noqa: BLE001 (the line keeps its GPU figures)
+                out['cpu_baseline'] = {'error': f'{type(e).__name__}: {e}'}
+                print(json.dumps(out))
+                if multi:
+                    dist.destroy_process_group()
+                return
             try:        # oracle speed / reference-Python speed, measured in the build container (tools/ref_ratio.py)
                 ratio = json.load(open(latest_profile('ref_vs_oracle_cpu.json')))['oracle_over_reference']
             except (OSError, KeyError, ValueError, TypeError):
