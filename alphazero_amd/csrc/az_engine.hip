@@ -997,7 +997,8 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
     int* ctr = reinterpret_cast<int*>(scr + S_WT);                       // FC_* words
     static_assert(8 * MAXIT * 2 >= 128 && (3 * FUSED_QUEUE + 32) * 4 <= 8 * 32 * 4, "LDS areas reused by the hand-off words");
     uint64_t* lbb = reinterpret_cast<uint64_t*>(scr + S_LBB);            // [64][2] leaf positions
-    const int wave_id = (int)blockIdx.x * FUSED_WAVES + uni(wave);         // (a scalar)
+    const int wave_u = uni(wave);          // (a scalar)
+    const int wave_id = (int)blockIdx.x * FUSED_WAVES + wave_u;
     if (wave == 0) {
         // the workgroup's games: the leading non-negative entries of its row of E.order; all start ready for
         // their first select
@@ -1110,7 +1111,7 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
             if (gpw <= FUSED_OWN_HEADS) {
                 // very few games: nobody to share a head batch with, so the worker runs its board's heads itself (its own
                 // logits area, no lock, no queue) and the game goes straight back to the ready queue
-                float* own_lg = reinterpret_cast<float*>(scr + FX_OWN + wave * FX_OWN_BYTES);
+                float* own_lg = reinterpret_cast<float*>(scr + FX_OWN + wave_u * FX_OWN_BYTES);
                 int* own_batch = reinterpret_cast<int*>(own_lg + 64);
                 if (tl == 0) own_batch[0] = g0;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
