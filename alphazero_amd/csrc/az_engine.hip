@@ -95,6 +95,7 @@ struct az_engine {
     Dev d;
     int A;
     int num_cus;        // compute units of cfg.device
+    int fused_wgs;      // workgroups az_c4_move_fused may use (0 = one per compute unit)
     uint32_t err_flags; // error bits seen by the last az_drain_finished
     double2* lut_dev;
 };
@@ -909,6 +910,9 @@ __global__ void __launch_bounds__(1024) k_fused_balance(Dev E, int gpw, int grid
 #define FX_END (FX_OWN + FUSED_WAVES * FX_OWN_BYTES)
 #endif
 #define FUSED_LDS_BYTES (OFF_BIAS + FX_END)
+// the engine's 512-byte counter block (E.ring_count, uint32 words): 0 finished games in the ring, 1 error bits,
+// 8..15 four 64-bit counters of this kernel (az_c4_move_fused_counters), 16..23 tuning builds, 64.. az_generic_select
+#define FUSED_COUNTER_WORD 8
 #define WATCHDOG_SPINS (1 << 20)       // x >= 128 cycles per poll: far beyond any wait of a healthy launch
 enum { FC_LEAF_HEAD = 0, FC_LEAF_TAIL, FC_DONE, FC_ABORT, FC_READY_HEAD, FC_READY_TAIL, FC_SEARCHING, FC_GAMES,
        FC_PLANES_HEAD, FC_PLANES_TAIL, FC_HEADS_LOCK, FC_PROGRESS,
@@ -1064,6 +1068,9 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
 #define TICK(acc) do { } while (0)
 #endif
     const bool few_games = gpw <= FUSED_FEW_GAMES;
+    // what this worker did (wave-uniform counts, added to the engine's counters when it leaves): two-board tasks,
+    // one-board tasks, head batches, boards in head batches
+    uint32_t did_pair = 0, did_single = 0, did_hbatch = 0, did_hboards = 0;
     for (int spins = 0, seen_progress = 0;;) {
         if (uni(lds_load(ctr + FC_ABORT)) || uni(lds_load(ctr + FC_DONE)) >= n_valid) break;
         const int lh = uni(lds_load(ctr + FC_LEAF_HEAD)), leaves = uni(lds_load(ctr + FC_LEAF_TAIL)) - lh;
@@ -1123,11 +1130,13 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
                 if (tl == 0) tstamp[g0] = (int)clock64();
 #endif
                 if (tl == 0) ring_push(readyq, ctr + FC_READY_TAIL, g0);
+                ++did_hbatch; ++did_hboards;
             } else if (lane == 0) {
                 ring_push(planeq, ctr + FC_PLANES_TAIL, g0);
                 if (g1 >= 0) ring_push(planeq, ctr + FC_PLANES_TAIL, g1);
             }
             TICK(t_task);
+            if (g1 >= 0) ++did_pair; else ++did_single;
 #ifdef AZ_EXP_TIMING
             if (g1 >= 0) ++n_pair; else ++n_single;
 #endif
@@ -1168,6 +1177,7 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
 #endif
                 if (hl < n) ring_push(readyq, ctr + FC_READY_TAIL, batch[hl]);
                 if (hl == 0) lds_add(ctr + FC_SEARCHING, -n);
+                ++did_hbatch; did_hboards += (uint32_t)n;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) lds_store(ctr + FC_HEADS_LOCK, 0);
@@ -1227,6 +1237,12 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
             }
             break;
         }
+    }
+    if (lane == 0) {
+        unsigned long long* fc = reinterpret_cast<unsigned long long*>(E.ring_count + FUSED_COUNTER_WORD);
+        if (did_pair) atomicAdd(fc + 0, (unsigned long long)did_pair);
+        if (did_single) atomicAdd(fc + 1, (unsigned long long)did_single);
+        if (did_hbatch) { atomicAdd(fc + 2, (unsigned long long)did_hbatch); atomicAdd(fc + 3, (unsigned long long)did_hboards); }
     }
 #ifdef AZ_EXP_TIMING
     TICK(t_idle);
@@ -1661,6 +1677,7 @@ int az_engine_create(const az_engine_config* cfg, az_engine** out) {
     e->cfg = *cfg;
     e->A = cfg->game == AZ_GAME_C4 ? GameC4::A : cfg->game == AZ_GAME_TTT ? GameTTT::A : GEN_A;
     e->num_cus = cus;
+    e->fused_wgs = 0;
     e->err_flags = 0;
     Dev& d = e->d;
     memset(&d, 0, sizeof(d));
@@ -1867,13 +1884,17 @@ int az_debug_counters(az_engine* e, unsigned long long* out12) {
 // games per workgroup of the one-launch-per-move kernel: spread over one workgroup per compute unit, at most
 // 64 (eight search lanes per game)
 #define FUSED_MAX_GPW 64
+static int fused_workgroups(const az_engine* e) {
+    return (e->fused_wgs > 0 && e->fused_wgs < e->num_cus) ? e->fused_wgs : e->num_cus;
+}
 static int fused_launch(az_engine* e, const uint8_t* blob, int32_t num_blocks, uint64_t* leaf_bb, int32_t* leaf_info,
                         float* p, float* v, hipStream_t st) {
     if (e->cfg.game != AZ_GAME_C4) return az_fail("az_c4_move_fused: Connect Four only");
     if (num_blocks < 0) return az_fail("az_c4_move_fused: num_blocks");
     if (e->d.S <= 0) return 0;
-    const int gpw = (e->d.G + e->num_cus - 1) / e->num_cus;
-    if (gpw > FUSED_MAX_GPW) return az_fail("az_c4_move_fused: more than 64 games per compute unit");
+    const int wgs = fused_workgroups(e);
+    const int gpw = (e->d.G + wgs - 1) / wgs;
+    if (gpw > FUSED_MAX_GPW) return az_fail("az_c4_move_fused: more than 64 games per workgroup");
     const int grid = (e->d.G + gpw - 1) / gpw;
     // already done by az_engine_create on this device (a bitmap test, then nothing)
     if (int rc = az_set_kernel_lds(reinterpret_cast<const void*>(k_c4_move_fused), FUSED_LDS_BYTES, g_fused_attr_done)) return rc;
@@ -1885,7 +1906,23 @@ static int fused_launch(az_engine* e, const uint8_t* blob, int32_t num_blocks, u
     return 0;
 }
 
-int az_c4_move_fused_max_games(const az_engine* e) { return e ? FUSED_MAX_GPW * e->num_cus : -1; }
+int az_c4_move_fused_max_games(const az_engine* e) { return e ? FUSED_MAX_GPW * fused_workgroups(e) : -1; }
+
+int az_c4_move_fused_limit_workgroups(az_engine* e, int32_t max_workgroups) {
+    if (!e || max_workgroups < 0) return az_fail("az_c4_move_fused_limit_workgroups: bad argument");
+    e->fused_wgs = max_workgroups;
+    return 0;
+}
+
+int az_c4_move_fused_counters(az_engine* e, uint64_t* out4, void* stream) {
+    if (!e || !out4) return az_fail("null argument");
+    ENGINE_SCOPE(e);
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(out4, e->d.ring_count + FUSED_COUNTER_WORD, 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemsetAsync(e->d.ring_count + FUSED_COUNTER_WORD, 0, 32, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
+}
 
 int az_c4_move_fused(az_engine* e, const uint8_t* blob, int32_t num_blocks, uint64_t* leaf_bb, int32_t* leaf_info,
                      float* p, float* v, void* stream) {

@@ -142,6 +142,18 @@ class SelfPlayEngine:
         """Largest engine that move_fused accepts on this device (64 games per compute unit)."""
         return int(self.lib.az_c4_move_fused_max_games(self.h))
 
+    def limit_fused_workgroups(self, max_workgroups):
+        """Cap the workgroups move_fused spreads the games over (0 = one per compute unit, the default)."""
+        check(self.lib.az_c4_move_fused_limit_workgroups(self.h, int(max_workgroups)))
+
+    def fused_counters(self):
+        """What move_fused's workgroups did since the last call: network tasks with two boards / one board,
+        head batches, boards in head batches (synchronises; resets the counters)."""
+        out = (C.c_uint64 * 4)()
+        check(self.lib.az_c4_move_fused_counters(self.h, out, self._stream()))
+        return {'pair_tasks': int(out[0]), 'single_tasks': int(out[1]), 'head_batches': int(out[2]),
+                'head_boards': int(out[3])}
+
     def move_fused(self, net):
         """All S simulations of the move in one launch with a FusedC4Net (after begin_move / apply_root)."""
         if self._pv is None:

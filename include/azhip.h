@@ -278,8 +278,19 @@ int  az_c4net128_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uin
  * when enabled.  Results are bit-identical to the stepwise loop with az_c4net_bf16_forward.          */
 int  az_c4_move_fused(az_engine* e, const uint8_t* blob, int32_t num_blocks, uint64_t* leaf_bb,
                       int32_t* leaf_info, float* p, float* v, void* stream);
-/* largest engine (games) az_c4_move_fused accepts on the engine's device: 64 games per compute unit */
+/* largest engine (games) az_c4_move_fused accepts on the engine's device: 64 games per workgroup, one
+ * workgroup per compute unit (or per az_c4_move_fused_limit_workgroups)                                 */
 int  az_c4_move_fused_max_games(const az_engine* e);
+/* No counterpart in the reference (which has one game per process, alphazero/train.py:131-134).  By default
+ * az_c4_move_fused spreads the engine's games over one workgroup per compute unit; this call caps the number
+ * of workgroups (0 = back to the default), e.g. to leave compute units to a training stream, or to put
+ * many games into each workgroup of a small engine.  How many games share a workgroup decides how its
+ * leaves are batched (alone, in pairs, heads per board or per batch) but never what a game's tree becomes. */
+int  az_c4_move_fused_limit_workgroups(az_engine* e, int32_t max_workgroups);
+/* What the workgroups of az_c4_move_fused did since the last call (or az_reset_games), HOST uint64[4]:
+ * network tasks with two boards, with one board, head batches, boards in head batches.  Synchronous;
+ * resets the counters.  No counterpart in the reference (alphazero/mcts.py:94-107 evaluates one leaf).   */
+int  az_c4_move_fused_counters(az_engine* e, uint64_t* out4_host, void* stream);
 
 /* az_c4_move_fused without its four staging arguments and without any allocation.  No counterpart in the
  * reference; for callers that cannot allocate device memory or pass a workspace: code under HIP graph capture,

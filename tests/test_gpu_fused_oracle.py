@@ -32,8 +32,18 @@ def _single_leaf_evaluator(net, memo):
     return fn
 
 
-@pytest.mark.parametrize('G,S,moves,depth', [(64, 48, 9, 4), (64, 200, 4, 2), (100, 33, 5, 3)])
-def test_fused_move_kernel_matches_the_oracle(G, S, moves, depth):
+# wgs = workgroups the launch may use (0 = one per compute unit, i.e. one game per workgroup for these sizes);
+# regime = how a workgroup with that many games evaluates its leaves (csrc/az_engine.hip, FUSED_FEW_GAMES /
+# FUSED_OWN_HEADS): 'own' = one board per task, heads by the same wave; 'single' = one board per task, heads in
+# shared batches; 'pairs' = two boards per task, heads in shared batches (what 8 192 games on 256 compute units run)
+@pytest.mark.parametrize('G,S,moves,depth,wgs,regime', [
+    (64, 48, 9, 4, 0, 'own'), (64, 200, 4, 2, 0, 'own'), (100, 33, 5, 3, 0, 'own'),
+    (96, 48, 5, 3, 8, 'single'),         # 12 games per workgroup
+    (256, 48, 5, 4, 8, 'pairs'),         # 32 games per workgroup
+    (256, 200, 2, 2, 4, 'pairs'),        # 64 games per workgroup, the most a workgroup takes
+    (250, 33, 3, 2, 5, 'pairs'),         # 50 per workgroup, the last one not full
+])
+def test_fused_move_kernel_matches_the_oracle(G, S, moves, depth, wgs, regime):
     from alphazero_amd import engine as E
     from alphazero_amd.models import AlphaZeroC4
     from alphazero_amd.net import FusedC4Net
@@ -47,6 +57,8 @@ def test_fused_move_kernel_matches_the_oracle(G, S, moves, depth):
 
     # ---- HIP: all games at once
     eng = E.SelfPlayEngine(E._lib.GAME_C4, G, S, exploration_depth=depth, reuse_search_tree=True, lut=lut_np, device=0)
+    eng.limit_fused_workgroups(wgs)
+    eng.fused_counters()
     got = []
     for mv in range(moves):
         bb, info = eng.begin_move()
@@ -61,6 +73,15 @@ def test_fused_move_kernel_matches_the_oracle(G, S, moves, depth):
         act, ne, vis, win = eng.choose_and_advance(torch.from_numpy(np.ascontiguousarray(us[:, mv])).cuda())
         got.append((act.cpu().numpy().copy(), ne.cpu().numpy().copy(), vis.cpu().numpy().copy(), roots))
     assert eng.stats()['errors'] == 0 and eng.error_flags() == 0
+    # the launches really ran in the regime this case is for
+    did = eng.fused_counters()
+    if regime == 'own':
+        assert did['pair_tasks'] == 0 and did['single_tasks'] > 0 and did['head_boards'] == did['head_batches']
+    elif regime == 'single':
+        assert did['pair_tasks'] == 0 and did['single_tasks'] > 0 and did['head_boards'] > 1.5 * did['head_batches'], did
+    else:
+        assert did['pair_tasks'] > 10 * did['single_tasks'] and did['head_boards'] > 2 * did['head_batches'], did
+    assert did['head_boards'] == 2 * did['pair_tasks'] + did['single_tasks']
     eng.close()
 
     # ---- oracle: one game at a time, the same eta / u per (game, move)
