@@ -186,13 +186,16 @@ __device__ __forceinline__ double puct_score(uint32_t N, float W, float P, doubl
     return (double)Q + U;
 }
 
-// beyond the host table: device libm (not bit-pinned to numpy); kept out of line
-__device__ __noinline__ double2 lut_slow(double c_base, double c_init, uint32_t Ns) {
-    return make_double2(log((double)(1ull + Ns + (uint64_t)c_base) / c_base) + c_init, sqrt((double)Ns));
-}
+// {Cs, sqrt(Ns)} of a node whose edges have Ns visits in all.  The table is the host's (az_set_puct_lut: the
+// reference's own numpy expressions), and a search never leaves it when it is sized as az_engine_create sizes it.
+// A visit sum beyond its last row takes the last row and raises error bit 3 in the engine's flag word: the device
+// has no logarithm that is bit-pinned to numpy's, so the search goes on but is reported as no longer exact.
 __device__ __forceinline__ double2 lut_fetch(const Dev& E, uint32_t Ns) {
-    if ((int32_t)Ns >= 0 && (int32_t)Ns < E.lut_len) return E.lut[Ns];
-    return lut_slow(E.c_base, E.c_init, Ns);
+    if (Ns >= (uint32_t)E.lut_len) {
+        atomicOr(E.ring_count + 1, 8u);
+        Ns = (uint32_t)E.lut_len - 1u;
+    }
+    return E.lut[Ns];
 }
 __device__ __forceinline__ void lut_lookup(const Dev& E, uint32_t Ns, double& cs, double& sq) {
     const double2 t = lut_fetch(E, Ns);
@@ -1373,6 +1376,12 @@ __global__ void __launch_bounds__(64) k_generic_select(Dev E, int g, uint32_t* o
         depth += 1;
         node = rdlane(e.w, slot);
     }
+    if (node != AZ_NO_NODE) {
+        // the path stack is full and the walk is still inside the tree: nothing may be expanded or backed up from
+        // here (it would replace an existing child and lose its subtree).  Error bit 5; the host call fails.
+        if (lane == 0) { s->leaf_depth = 0; s->leaf_kind = AZ_LEAF_NONE; out[0] = 0xFFFFFFFFu; atomicOr(E.ring_count + 1, 32u); }
+        return;
+    }
     if (lane == 0) { s->leaf_depth = depth; s->leaf_kind = AZ_LEAF_EVAL; out[0] = (uint32_t)depth; s->st_steps += (uint64_t)depth; }
 }
 
@@ -1688,7 +1697,21 @@ int az_engine_create(const az_engine_config* cfg, az_engine** out) {
     d.seed = cfg->seed; d.first_uid = cfg->first_game_uid;
     d.uid_stride = cfg->uid_stride ? cfg->uid_stride : (uint64_t)cfg->num_games;
     d.ring_cap = 2u * (uint32_t)cfg->num_games + 16u;
-    const int rc = engine_alloc(e);
+    int rc = engine_alloc(e);
+    if (!rc) {
+        // A table for every visit sum a search of this engine can reach, from the host's libm; callers that need
+        // the reference's bits (numpy's log) replace it with az_set_puct_lut.
+        long reach = cfg->game == AZ_GAME_GENERIC ? cap + 2
+                                                  : (long)cfg->num_simulations * (cfg->reuse_search_tree ? lmax : 1) + 2;
+        if (reach < 1024) reach = 1024;
+        if (reach > (1l << 24)) reach = 1l << 24;
+        std::vector<double> t((size_t)2 * reach);
+        for (long i = 0; i < reach; ++i) {
+            t[2 * i] = log((1.0 + (double)i + cfg->c_base) / cfg->c_base) + cfg->c_init;
+            t[2 * i + 1] = sqrt((double)i);
+        }
+        rc = az_set_puct_lut(e, t.data(), (int32_t)reach);
+    }
     if (rc) {                         // nothing is handed out half-built: free what was allocated
         const std::string why = g_err;
         az_engine_destroy(e);
@@ -2049,8 +2072,13 @@ int az_generic_select(az_engine* e, int32_t g, int32_t* depth_host, uint8_t* slo
     uint32_t host[1 + PATH_LEN];
     HIPCHK(hipMemcpyAsync(host, out, sizeof(host), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    if (host[0] > PATH_LEN) {
+        e->err_flags |= 32u;
+        *depth_host = 0;
+        return az_fail("az_generic_select: the search path is deeper than 48 levels (the tree is unchanged; search from a node nearer the leaves)");
+    }
     *depth_host = (int32_t)host[0];
-    for (uint32_t d = 0; d < host[0] && d < PATH_LEN; ++d) slots_host[d] = (uint8_t)host[1 + d];
+    for (uint32_t d = 0; d < host[0]; ++d) slots_host[d] = (uint8_t)host[1 + d];
     return 0;
 }
 
@@ -2108,6 +2136,9 @@ int az_get_tree(az_engine* e, int32_t g, uint32_t* nodes_host, int32_t max_nodes
     HIPCHK(hipDeviceSynchronize());
     Slot s;
     HIPCHK(hipMemcpy(&s, e->d.slots + g, sizeof(Slot), hipMemcpyDeviceToHost));
+    uint32_t flags = 0;               // this call has synchronised anyway: bring az_engine_error_flags up to date
+    HIPCHK(hipMemcpy(&flags, e->d.ring_count + 1, 4, hipMemcpyDeviceToHost));
+    e->err_flags |= flags | s.err;
     *num_nodes = (int32_t)s.alloc; *root_node = s.root;
     if (!nodes_host) return 0;
     if ((int32_t)s.alloc > max_nodes) return az_fail("az_get_tree: buffer too small");

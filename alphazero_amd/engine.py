@@ -85,6 +85,13 @@ class SelfPlayEngine:
         lut = np.ascontiguousarray(lut, dtype=np.float64)
         assert lut.ndim == 2 and lut.shape[1] == 2
         check(self.lib.az_set_puct_lut(self.h, C.c_void_p(lut.ctypes.data), lut.shape[0]))
+        self.lut_len = int(lut.shape[0])
+
+    def ensure_puct_lut(self, reach):
+        """Make sure the PUCT table has a row for every visit sum up to `reach` (the device computes no
+        logarithm: past the table's end it would reuse the last row and raise error bit 3)."""
+        if reach > self.lut_len:
+            self.set_puct_lut(make_puct_lut(max(int(reach), 2 * self.lut_len), self.cfg.c_base, self.cfg.c_init))
 
     def set_model_version(self, v):
         check(self.lib.az_set_model_version(self.h, int(v)))
@@ -209,8 +216,10 @@ class SelfPlayEngine:
         return [GameRecord.from_buffer_copy(raw[i].tobytes()) for i in range(raw.shape[0])]
 
     def error_flags(self):
-        """Error bits seen by the drains since the last reset: 1 = a node pool ran out, 2 = finished
-        games were dropped because the record ring was full.  No device work."""
+        """Error bits seen by the drains (and get_tree) since the last reset: 1 = a node pool ran out, 2 =
+        finished games were dropped because the record ring was full, 8 = a visit sum beyond the PUCT table,
+        16 = move_fused abandoned a launch, 32 = a user-defined game's search path deeper than 48 levels.
+        No device work."""
         return int(self.lib.az_engine_error_flags(self.h))
 
     def stats(self):

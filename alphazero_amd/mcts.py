@@ -241,6 +241,7 @@ def _run_mcts_generic(game, root, model, num_simulations, alpha, epsilon):
         raise TypeError(f'run_mcts: user-defined games may have up to {A} actions, got {game.NUM_ACTIONS}')
     img, objs = _flatten(root, A)
     eng = _single_engine(_lib.GAME_GENERIC, float(alpha), float(epsilon), img.shape[0] + num_simulations + 2)
+    eng.ensure_puct_lut(_visits_below(root) + num_simulations + 2)
     eng.set_position(0, 0, 0, len(game), img if len(objs) else None, 0 if len(objs) else NO_NODE)
     # mcts.py:114-117
     p_root = None
@@ -252,7 +253,12 @@ def _run_mcts_generic(game, root, model, num_simulations, alpha, epsilon):
     eng.generic_root(0, p_root, np.random.dirichlet([alpha] * n_edges))
     for _ in range(num_simulations):
         simulation = game.clone()
-        for ai in eng.generic_select(0):                       # mcts.py:123-127
+        try:
+            path = eng.generic_select(0)                       # mcts.py:123-127
+        except _lib.AzError:
+            eng.reset_games()                                  # clears the engine's error word; `root` is untouched
+            raise
+        for ai in path:
             simulation.take_action(simulation.valid_actions[ai])
         if simulation.terminal:                                # mcts.py:131-134
             eng.generic_expand_backup(0, None, simulation.terminal_value(simulation.prev_player))
@@ -262,7 +268,20 @@ def _run_mcts_generic(game, root, model, num_simulations, alpha, epsilon):
             assert abs(float(np.sum(p)) - 1) < 1e-6, f'Node must be expanded with normalized distribution. Got: {p}'
             eng.generic_expand_backup(0, p, -np.float32(v))
     st_img, root_idx = eng.get_tree(0)
+    _check_flags(eng)
     _unflatten(st_img, objs, root, root_idx, A)
+
+
+def _visits_below(root):
+    return int(np.sum(root.num_visits)) if root.expanded else 0
+
+
+def _check_flags(eng):
+    flags = eng.error_flags()
+    if flags:
+        eng.reset_games()            # (clears the flag word; the slot is loaded afresh by the next search)
+        raise _lib.AzError(f'run_mcts: the engine reported error bits {flags:#x} (1 = node pool exhausted, '
+                           '8 = visit sum beyond the PUCT table, 32 = search path deeper than 48 levels)')
 
 
 def run_mcts(game, root, model, num_simulations, alpha=0.3, epsilon=0.25):
@@ -276,6 +295,7 @@ def run_mcts(game, root, model, num_simulations, alpha=0.3, epsilon=0.25):
     img, objs = _flatten(root, A)
     eng = _single_engine(game_id, float(alpha), float(epsilon), img.shape[0] + num_simulations + 2)
     nx, pv, nm = game.position()
+    eng.ensure_puct_lut(_visits_below(root) + num_simulations + 2)
     eng.set_position(0, nx, pv, nm, img if len(objs) else None, 0 if len(objs) else NO_NODE)
     dev = eng.device
 
@@ -314,4 +334,5 @@ def run_mcts(game, root, model, num_simulations, alpha=0.3, epsilon=0.25):
             v[0] = val.reshape(-1)[0].to(dev, torch.float32)
         eng.expand_backup(p, v)
     st_img, root_idx = eng.get_tree(0)
+    _check_flags(eng)
     _unflatten(st_img, objs, root, root_idx, A)

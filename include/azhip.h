@@ -105,7 +105,11 @@ int  az_engine_destroy(az_engine* e);
 int  az_reset_games(az_engine* e, void* stream);
 /* PUCT table, HOST pointer, n rows of {Cs, sqrt(Ns)} indexed by Ns = sum N
  * (mcts.py:55-57 evaluated by the host's numpy, so the transcendental is the
- * reference's own).  Synchronous.                                            */
+ * reference's own).  Synchronous.  az_engine_create installs a table from the
+ * C library's log that covers every visit sum the engine's searches can reach
+ * (num_simulations * max moves with tree reuse); the device never computes a
+ * logarithm itself: a visit sum beyond the table's last row uses that row and
+ * raises error bit 3 (az_engine_error_flags).                                */
 int  az_set_puct_lut(az_engine* e, const double* lut_host, int32_t n);
 int  az_set_model_version(az_engine* e, int32_t version);
 
@@ -170,8 +174,11 @@ int  az_get_stats(az_engine* e, az_stats* out_host, void* stream);
  * game's node pool ran out (its later simulations are lost), bit 1 = the record ring overflowed (finished
  * games were dropped: drain more often), bit 4 = a wave of az_c4_move_fused found nothing to do for far
  * longer than any healthy launch lets it wait and the launch was abandoned (a fault in the library or
- * the device; that move's searches are incomplete).  Host-side read, no device work; -1 for a null
- * engine.  The reference cannot fail this way (it allocates per node and per game).                    */
+ * the device; that move's searches are incomplete), bit 3 = a node's visit sum went beyond the PUCT table
+ * (az_set_puct_lut: install a longer one; scores past the end used the last row), bit 5 = a search path of
+ * a user-defined game was deeper than 48 levels (az_generic_select failed and left the tree alone).  Also
+ * brought up to date by az_get_tree.  Host-side read, no device work; -1 for a null engine.  The reference
+ * cannot fail this way (it allocates per node and per game).                                            */
 int  az_engine_error_flags(const az_engine* e);
 
 /* Training examples of finished games, built on the device: what ReplayBufferDataset.__getitem__

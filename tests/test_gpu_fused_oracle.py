@@ -78,9 +78,9 @@ def test_fused_move_kernel_matches_the_oracle(G, S, moves, depth, wgs, regime):
     if regime == 'own':
         assert did['pair_tasks'] == 0 and did['single_tasks'] > 0 and did['head_boards'] == did['head_batches']
     elif regime == 'single':
-        assert did['pair_tasks'] == 0 and did['single_tasks'] > 0 and did['head_boards'] > 1.5 * did['head_batches'], did
+        assert did['pair_tasks'] == 0 and did['single_tasks'] > 0 and did['head_boards'] > did['head_batches'], did
     else:
-        assert did['pair_tasks'] > 10 * did['single_tasks'] and did['head_boards'] > 2 * did['head_batches'], did
+        assert did['pair_tasks'] > 4 * did['single_tasks'] and did['head_boards'] > 1.5 * did['head_batches'], did
     assert did['head_boards'] == 2 * did['pair_tasks'] + did['single_tasks']
     eng.close()
 

@@ -45,3 +45,33 @@ def test_masked_softmax_matches_torch():
             # tolerance: 1e-5 relative, the bound stated for net outputs in fp32
             assert torch.allclose(p[i][m], ref, rtol=1e-5, atol=1e-7)
             assert torch.all(p[i][~m] == 0)
+
+
+def test_production_lut_equals_the_golden_table_on_this_host():
+    """The default PUCT table (engine.make_puct_lut, this host's numpy) has the bits of the committed golden table:
+    the one transcendental of the search is the same on the box that runs the benchmark as where the goldens
+    were recorded."""
+    from alphazero_amd import engine as E
+    lut = load_lut()
+    assert E.make_puct_lut(lut.shape[0]).tobytes() == lut.tobytes()
+
+
+def test_visit_sum_beyond_the_table_is_reported_not_computed():
+    """The device has no logarithm pinned to numpy's: a search that outgrows its PUCT table keeps going on the
+    table's last row and says so (error bit 3), instead of silently leaving the pinned numerics."""
+    import torch
+    from alphazero_amd import engine as E
+    eng = E.SelfPlayEngine(E._lib.GAME_C4, 4, 40, reuse_search_tree=False, lut=E.make_puct_lut(16), device=0)
+    eng.begin_move_uniform()
+    eng.run_sims_uniform(40)
+    eng.choose_and_advance()
+    eng.drain_finished()
+    assert eng.error_flags() & 8
+    eng.close()
+    eng = E.SelfPlayEngine(E._lib.GAME_C4, 4, 40, reuse_search_tree=False, device=0)      # default table: long enough
+    eng.begin_move_uniform()
+    eng.run_sims_uniform(40)
+    eng.choose_and_advance()
+    eng.drain_finished()
+    assert eng.error_flags() == 0
+    eng.close()

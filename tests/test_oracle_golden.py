@@ -77,7 +77,15 @@ def test_lut_matches_host_numpy():
     ns = np.arange(lut.shape[0], dtype=np.uint64)
     assert np.array_equal(lut[:, 1], np.sqrt(ns))
     cs = np.array([np.log((1 + n + 19652) / 19652) + 1.25 for n in ns])
-    assert np.max(np.abs(cs - lut[:, 0])) < 1e-15
+    assert cs.tobytes() == lut[:, 0].tobytes()
+
+
+def test_production_lut_equals_the_golden_table_bit_for_bit():
+    # what SelfPlayEngine installs by default (vectorised numpy) against the table the goldens were made with
+    # (the reference's scalar expression, one Ns at a time): the same bits, row by row
+    from alphazero_amd.engine import make_puct_lut
+    lut = load_lut()
+    assert make_puct_lut(lut.shape[0]).tobytes() == lut.tobytes()
 
 
 def _replay(case, lut, evaluator):
