@@ -42,6 +42,7 @@ def _single_leaf_evaluator(net, memo):
     (256, 48, 5, 4, 8, 'pairs'),         # 32 games per workgroup
     (256, 200, 2, 2, 4, 'pairs'),        # 64 games per workgroup, the most a workgroup takes
     (250, 33, 3, 2, 5, 'pairs'),         # 50 per workgroup, the last one not full
+    (512, 200, 3, 3, 16, 'pairs'),       # 32 per workgroup on 16 workgroups, 200 simulations
 ])
 def test_fused_move_kernel_matches_the_oracle(G, S, moves, depth, wgs, regime):
     from alphazero_amd import engine as E

@@ -12,7 +12,12 @@ def test_ucb_score_bits_match_reference():
     from alphazero_amd import engine as E
     from alphazero_amd._lib import check, ptr
     cases = load_json('nodes.json')
-    eng = E.SelfPlayEngine(0, 1, 1, lut=load_lut())          # TTT: 9 edge slots
+    # some of the recorded nodes have more visits than the committed table has rows: the table is extended by the
+    # same host expression (its first rows are the committed bits)
+    reach = max(sum(c['N']) for c in cases) + 1
+    lut = E.make_puct_lut(max(reach, load_lut().shape[0]))
+    assert lut[:load_lut().shape[0]].tobytes() == load_lut().tobytes()
+    eng = E.SelfPlayEngine(0, 1, 1, lut=lut)                 # TTT: 9 edge slots
     n, A = len(cases), 9
     N = np.zeros((n, A), np.uint32); W = np.zeros((n, A), np.float32); P = np.zeros((n, A), np.float32)
     ne = np.zeros(n, np.int32)
