@@ -118,6 +118,16 @@ struct DeviceScope {
     DeviceScope _scope((e)->cfg.device);                                       \
     if (_scope.err != hipSuccess) return az_fail("selecting the engine's device", _scope.err)
 
+// Diagnostic builds (-DAZ_EXP_ASSERT): every index that addresses a node pool, a slot, a queue or a plane is
+// checked before use.  The first violation is recorded in the engine's counter block (words 24..27: code, value,
+// workgroup, thread), error bit 6 is raised, and the access is skipped, so that a wrong index names itself
+// instead of ending the launch with a memory fault.  Product builds compile the checks away.
+#ifdef AZ_EXP_ASSERT
+#define AZ_IDX_OK(E_, ok, code, val) az_idx_ok((E_), (ok), (code), (uint32_t)(val))
+#else
+#define AZ_IDX_OK(E_, ok, code, val) true
+#endif
+
 // ---------------------------------------------------------------------------
 // wave helpers
 // ---------------------------------------------------------------------------
@@ -186,16 +196,38 @@ __device__ __forceinline__ double puct_score(uint32_t N, float W, float P, doubl
     return (double)Q + U;
 }
 
+#ifdef AZ_EXP_ASSERT
+__device__ __forceinline__ bool az_idx_ok(const Dev& E, bool ok, uint32_t code, uint32_t val) {
+    if (!ok) {
+        uint32_t* dbg = E.ring_count + 24;
+        if (atomicCAS(dbg, 0u, code) == 0u) { dbg[1] = val; dbg[2] = blockIdx.x; dbg[3] = threadIdx.x; }
+        atomicOr(E.ring_count + 1, 64u);
+    }
+    return ok;
+}
+#endif
+#ifdef AZ_EXP_LUT_CALL
+// diagnostic builds only: the out-of-line call that the search step used to contain (never taken when the table
+// covers the search), to compare spilling builds with and without a call in the kernel
+__device__ __noinline__ double2 lut_slow(double c_base, double c_init, uint32_t Ns) {
+    return make_double2(log((double)(1ull + Ns + (uint64_t)c_base) / c_base) + c_init, sqrt((double)Ns));
+}
+#endif
 // {Cs, sqrt(Ns)} of a node whose edges have Ns visits in all.  The table is the host's (az_set_puct_lut: the
 // reference's own numpy expressions), and a search never leaves it when it is sized as az_engine_create sizes it.
 // A visit sum beyond its last row takes the last row and raises error bit 3 in the engine's flag word: the device
 // has no logarithm that is bit-pinned to numpy's, so the search goes on but is reported as no longer exact.
 __device__ __forceinline__ double2 lut_fetch(const Dev& E, uint32_t Ns) {
+#ifdef AZ_EXP_LUT_CALL
+    if ((int32_t)Ns >= 0 && (int32_t)Ns < E.lut_len) return E.lut[Ns];
+    return lut_slow(E.c_base, E.c_init, Ns);
+#else
     if (Ns >= (uint32_t)E.lut_len) {
         atomicOr(E.ring_count + 1, 8u);
         Ns = (uint32_t)E.lut_len - 1u;
     }
     return E.lut[Ns];
+#endif
 }
 __device__ __forceinline__ void lut_lookup(const Dev& E, uint32_t Ns, double& cs, double& sq) {
     const double2 t = lut_fetch(E, Ns);
@@ -538,6 +570,7 @@ __device__ __forceinline__ void select_leaf_g(const Dev& E, const uint4* pool, u
     double2 lt = make_double2(0.0, 0.0);
     if (active) lt = lut_fetch(E, hint);
     uint4 e = make_uint4(0u, 0u, 0u, AZ_NO_NODE);
+    if (active && !AZ_IDX_OK(E, node < (uint32_t)E.cap, 3, node)) active = false;
     if (active && sub < AS) e = pool[(size_t)node * AS + sub];
     while (active) {
         const int n_edges = (int)G_::bcast(e.x, AS - 1);
@@ -555,12 +588,13 @@ __device__ __forceinline__ void select_leaf_g(const Dev& E, const uint4* pool, u
         // the child's line and its table entry are requested here, so that stepping the position and
         // the win test below run while they travel
         uint4 e_next = make_uint4(0u, 0u, 0u, AZ_NO_NODE);
-        if (child != AZ_NO_NODE) {
+        if (child != AZ_NO_NODE && AZ_IDX_OK(E, child < (uint32_t)E.cap, 1, child)) {
             lt = lut_fetch(E, hint);
             if (sub < AS) e_next = pool[(size_t)child * AS + sub];
         }
         const int action = az_nth_set_bit(GM::legal(nx, pv), slot);    // mcts.py:126
-        if (sub == 0) path[depth] = (node << 4) | (uint32_t)slot;
+        if (sub == 0 && AZ_IDX_OK(E, depth < PATH_LEN && slot >= 0 && slot < AS, 2, (depth << 8) | (slot & 255)))
+            path[depth] = (node << 4) | (uint32_t)slot;
         depth += 1;
         steps += 1;
         GM::play(nx, pv, nm, action);
@@ -605,9 +639,10 @@ __device__ __forceinline__ uint32_t expand_node_g(const Dev& E, uint4* pool, uin
 
 // mcts.py:84-86 for one path level: W += v (fp32), N += 1, and the node's cached sum N
 template <class GM>
-__device__ __forceinline__ void backup_edge(uint4* pool, uint32_t ent, float v) {
+__device__ __forceinline__ void backup_edge(const Dev& E, uint4* pool, uint32_t ent, float v) {
     constexpr int AS = GM::A + 1;
     const uint32_t node = ent >> 4, slot = ent & 15u;
+    if (!AZ_IDX_OK(E, node < (uint32_t)E.cap && slot < (uint32_t)AS, 4, ent)) return;
     uint2* ep = reinterpret_cast<uint2*>(&pool[(size_t)node * AS + slot]);
     uint32_t* ns = reinterpret_cast<uint32_t*>(&pool[(size_t)node * AS + AS - 1]) + 1;
     uint2 nw = *ep;                       // both loads are issued before either store
@@ -619,9 +654,9 @@ __device__ __forceinline__ void backup_edge(uint4* pool, uint32_t ent, float v) 
 }
 // mcts.py:147-158: the group's lanes take path levels sub, sub+GS, ... (levels are distinct nodes)
 template <class GM, int GS>
-__device__ __forceinline__ void backup_g(uint4* pool, int depth, const uint32_t* path, float v_leaf_edge, int sub) {
+__device__ __forceinline__ void backup_g(const Dev& E, uint4* pool, int depth, const uint32_t* path, float v_leaf_edge, int sub) {
     for (int d = sub; d < depth; d += GS)
-        backup_edge<GM>(pool, path[d], ((depth - 1 - d) & 1) ? -v_leaf_edge : v_leaf_edge);
+        backup_edge<GM>(E, pool, path[d], ((depth - 1 - d) & 1) ? -v_leaf_edge : v_leaf_edge);
 }
 
 #define GROUP_PROLOGUE                                                                   \
@@ -669,7 +704,8 @@ __device__ __forceinline__ int sim_step_game(const Dev& E, const float* p, const
     uint32_t sims = 0, evals = 0, steps = 0;
 
     if (DO_EXPAND && (kind == AZ_LEAF_EVAL || kind == AZ_LEAF_CACHED)) {
-        const int depth = (int)h3.y;
+        int depth = (int)h3.y;
+        if (!AZ_IDX_OK(E, depth >= 1 && depth <= PATH_LEN, 5, depth)) depth = 1;
         if (E.cache && kind == AZ_LEAF_EVAL) {                       // remember what the evaluator said
             const int w0 = 4 * sub - 6;                              // index into p of this lane's word .x
             uint32_t w[4];
@@ -704,15 +740,15 @@ __device__ __forceinline__ int sim_step_game(const Dev& E, const float* p, const
             const uint32_t l2 = s->path[dl];
             if (sub == 0 && idx != AZ_NO_NODE)
                 reinterpret_cast<uint32_t*>(&pool[(size_t)(l2 >> 4) * AS + (l2 & 15u)])[3] = idx;
-        } else if (idx != AZ_NO_NODE && sub == 0) {
+        } else if (idx != AZ_NO_NODE && sub == 0 && AZ_IDX_OK(E, (last >> 4) < (uint32_t)E.cap && (last & 15u) < (uint32_t)AS, 6, last)) {
             reinterpret_cast<uint32_t*>(&pool[(size_t)(last >> 4) * AS + (last & 15u)])[3] = idx;
         }
         // mcts.py:144-158: v *= -1, then one level per lane
         const float vb = -v_g;
-        if (sub < depth) backup_edge<GM>(pool, pa, ((depth - 1 - sub) & 1) ? -vb : vb);
-        if (GS < PATH_LEN && sub + GS < depth) backup_edge<GM>(pool, pb, ((depth - 1 - sub - GS) & 1) ? -vb : vb);
+        if (sub < depth) backup_edge<GM>(E, pool, pa, ((depth - 1 - sub) & 1) ? -vb : vb);
+        if (GS < PATH_LEN && sub + GS < depth) backup_edge<GM>(E, pool, pb, ((depth - 1 - sub - GS) & 1) ? -vb : vb);
         for (int d = sub + 2 * GS; d < depth; d += GS)
-            backup_edge<GM>(pool, s->path[d], ((depth - 1 - d) & 1) ? -vb : vb);
+            backup_edge<GM>(E, pool, s->path[d], ((depth - 1 - d) & 1) ? -vb : vb);
         sims += 1; evals += 1;
         kind = AZ_LEAF_NONE;
     }
@@ -756,7 +792,7 @@ __device__ __forceinline__ int sim_step_game(const Dev& E, const float* p, const
             }
         }
         if (kind == AZ_LEAF_TERMINAL) {
-            backup_g<GM, GS>(pool, depth, path, vterm, sub);
+            backup_g<GM, GS>(E, pool, depth, path, vterm, sub);
             sims += 1;
         } else if (!PATH_IN_SLOT && (kind == AZ_LEAF_EVAL || kind == AZ_LEAF_CACHED)) {
             for (int d = sub; d < depth; d += GS) s->path[d] = path[d];
@@ -970,7 +1006,10 @@ __device__ unsigned long long g_wait_dbg[10];
 __device__ unsigned long long g_wg_dbg[2 * 1024];     // per workgroup of the last launch: cycles until its last game was done, boards evaluated
 __device__ unsigned long long g_done_dbg[8];     // cycles from the start until 1 / 50 % / 75 % / 90 % / all games of a workgroup are done
 #endif
-__global__ void __launch_bounds__(FUSED_THREADS, FUSED_WAVES / 4)
+#ifndef FUSED_MIN_WAVES       // waves per SIMD the register budget is cut for; diagnostic builds raise it to make the
+#define FUSED_MIN_WAVES (FUSED_WAVES / 4)     // kernel spill (3: 168 registers, 4: 128)
+#endif
+__global__ void __launch_bounds__(FUSED_THREADS, FUSED_MIN_WAVES)
 k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, int32_t* leaf_info, float* p,
                 float* v, int num_sims, int gpw) {
     constexpr int GS = 8;
@@ -1031,7 +1070,9 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
 #endif
     auto step = [&](int lane, int gl, auto tag_expand, bool sel) {
         const int sub = lane & (GS - 1);
+        if (!AZ_IDX_OK(E, gl >= 0 && gl < 64, 7, gl)) return;
         const int g = gmap[gl];
+        if (!AZ_IDX_OK(E, g >= 0 && g < E.G, 8, g)) return;
         Slot* s = E.slots + g;
         uint4* pool = E.pool + (size_t)g * E.cap * (GameC4::A + 1);
         const int kind = sim_step_game<GameC4, GS, decltype(tag_expand)::value, true, true>(
@@ -1099,6 +1140,7 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
             if (lane == 0) lds_add(ctr + FC_BOARDS, take);
             const long long task_t0 = clock64();
 #endif
+            if (!AZ_IDX_OK(E, g0 >= 0 && g0 < 64 && g1 >= -1 && g1 < 64, 9, (g0 << 8) | (g1 & 255))) break;
             __bf16* hp0 = reinterpret_cast<__bf16*>(planes + g0 * PLANE_SLOT);
             const int tl = phase_lane(lane);
             if (g1 >= 0) {
@@ -1165,6 +1207,7 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
                     int x;
                     while ((x = lds_load(slot)) == 0) __builtin_amdgcn_s_sleep(1);      // its writer is one store behind
                     lds_store(slot, 0);
+                    if (!AZ_IDX_OK(E, x >= 1 && x <= 64, 10, x)) x = 1;
                     batch[hl] = x - 1;
 #ifdef AZ_EXP_TIMING
                     w_plane += (unsigned)((int)clock64() - tstamp[x - 1]); ++n_plane;
@@ -1297,10 +1340,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_run_uniform_p(Dev E, int num_
             const uint32_t last = path[depth - 1];
             if (idx != AZ_NO_NODE && sub == 0)
                 reinterpret_cast<uint32_t*>(&pool[(size_t)(last >> 4) * (GM::A + 1) + (last & 15u)])[3] = idx;
-            backup_g<GM, GS>(pool, depth, path, -0.0f, sub);           // v = 0, then v *= -1
+            backup_g<GM, GS>(E, pool, depth, path, -0.0f, sub);           // v = 0, then v *= -1
             evals += 1;
         } else if (kind == AZ_LEAF_TERMINAL) {
-            backup_g<GM, GS>(pool, depth, path, vterm, sub);
+            backup_g<GM, GS>(E, pool, depth, path, vterm, sub);
         }
         sims += 1;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");        // own stores before next select's loads
@@ -1900,6 +1943,15 @@ int az_debug_counters(az_engine* e, unsigned long long* out12) {
     HIPCHK(hipMemcpyFromSymbol(out12 + 4, HIP_SYMBOL(g_net_dbg), 64));
     unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_net_dbg), z, 64));
+    return 0;
+}
+#endif
+
+#ifdef AZ_EXP_ASSERT
+// diagnostic builds: the first failed index check {code, value, workgroup, thread}, zeros if none
+int az_debug_assert_words(az_engine* e, uint32_t* out4) {
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out4, e->d.ring_count + 24, 16, hipMemcpyDeviceToHost));
     return 0;
 }
 #endif

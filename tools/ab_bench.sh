@@ -1,9 +1,8 @@
 #!/bin/bash
 # A/B timing of builds of libazhip.so on ONE GPU box (boxes differ by a few per cent, so builds are only ever
 # compared inside one call): tools/ab_bench.sh <rounds> <a.so> <b.so> [...]   -> ms per step and per move launch.
-# Build variants beforehand, e.g.
-#   (cd alphazero_amd/csrc && hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -shared -DSOME_KNOB=1 \
-#        -o ../../variant.so az_engine.hip az_net.hip az_net_f32.hip az_net128.hip az_net_ttt.hip az_train.hip)
+# Build variants beforehand THROUGH THE MAKEFILE, so that its checks of the device assembly apply to them too, e.g.
+#   make -C alphazero_amd/csrc -j6 OUT=../variants/knob.so EXTRA="-DSOME_KNOB=1"
 # and run this on the GPU box; every bench run has its own time limit and the script stops at the first failure.
 set -e
 ROUNDS=$1; shift

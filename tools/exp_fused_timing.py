@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Phase split of the one-launch-per-move kernel (tuning aid).  Needs a library built with the cycle
 counters compiled in:
-    make -C alphazero_amd/csrc HIPFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -DAZ_EXP_TIMING"
+    make -C alphazero_amd/csrc -j6 OUT=../variants/timing.so EXTRA=-DAZ_EXP_TIMING ALLOW_SCRATCH=1
+    AZHIP_LIBRARY=alphazero_amd/variants/timing.so python tools/exp_fused_timing.py
 and prints, per move, how the waves' cycles divide into network tasks, search steps and idling, and how many
-tasks had two leaves.  Rebuild without the flag afterwards."""
+tasks had two leaves."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
