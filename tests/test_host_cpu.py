@@ -174,6 +174,50 @@ def test_model_server_and_checkpoint_format(tmp_path):
     assert srv.latest(b) == 0
 
 
+@pytest.mark.parametrize('idx', [0, 1])
+def test_checkpoint_is_what_the_reference_loader_accepted(tmp_path, idx):
+    """tests/golden/checkpoint.json was recorded by handing a checkpoint written by THIS package's
+    ModelServer to the reference's own loader (alphazero/eval.py:135-141: strict load_state_dict into the
+    reference's module built from its config file).  Written again from the same seed, the file must have
+    exactly the keys / shapes / dtypes the reference module took, alias the tower's one block the same
+    way, carry the same numbers, and this package's module loaded from it must return what the reference
+    module returned on the recorded positions."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import make_golden_ckpt as G
+    from alphazero_amd.model_server import ModelServer, load_ckpt
+    case = load_json('checkpoint.json')[idx]
+    assert (case['seed'], case['version']) == (G.SEED, G.VERSION)
+    model, shape = G.build(case['game'])
+    ModelServer(str(tmp_path), ckpt_period=1).update(model, case['version'])
+    path = tmp_path / 'ckpt' / f"{case['version']:06d}.pt"
+    ck = torch.load(path, weights_only=True)
+    assert ck['model_version'] == case['file_version'] == case['version']
+    sd = ck['model_state_dict']
+    assert [[k, list(v.shape), str(v.dtype)] for k, v in sd.items()] == case['keys']
+    for k, total in case['tensor_sums'].items():
+        assert float(sd[k].double().sum()) == total, k
+    # the reference's module aliases every tower block to one set of tensors; so does the file
+    storage = {}
+    for k, v in sd.items():
+        storage.setdefault(v.data_ptr(), []).append(k)
+    assert sorted(sorted(g) for g in storage.values() if len(g) > 1) == case['shared']
+    # a fresh module of this package loaded from the file evaluates like the reference's module did
+    fresh, _ = G.build(case['game'])
+    with torch.no_grad():
+        for prm in fresh.parameters():
+            prm.zero_()
+    assert load_ckpt(path, fresh) == case['version']
+    n = case['n']
+    A = 7 if case['game'] == 'c4' else 9
+    x = torch.from_numpy(unhex(case['x'], '<f4').reshape((n,) + shape).copy())
+    valid = torch.from_numpy(unhex(case['valid'], 'u1').reshape(n, A).astype(bool))
+    with torch.no_grad():
+        logits, v = fresh.eval()(x, valid)
+    assert np.allclose(logits.numpy().ravel(), unhex(case['logits'], '<f4'), rtol=1e-6, atol=1e-6)
+    assert np.allclose(v.numpy().ravel(), unhex(case['v'], '<f4'), rtol=1e-6, atol=1e-6)
+
+
 def test_mirror_networks_reproduce_the_reference_outputs():
     """Every (p, v) the reference's own networks returned while the golden games were played
     (alphazero/mcts.py:94-107 on alphazero/models.py, connectfour.py:31-72) against the mirror modules
