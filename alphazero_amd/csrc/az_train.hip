@@ -88,6 +88,25 @@ k_sgd_lr_dev(float* __restrict__ p, const float* __restrict__ g, float* __restri
     p[i] = fmaf(-lr, b, p[i]);
 }
 
+// k_sgd_lr_dev behind a guard that is also read from device memory: when !(guard[0] < limit) -- a failed check of
+// the batch, NaN included -- nothing is updated and withheld[0] counts the step
+__global__ void __launch_bounds__(256)
+k_sgd_guarded(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, long n,
+              const float* __restrict__ lr_dev, float momentum, float wd, const float* __restrict__ guard, float limit,
+              int* __restrict__ withheld) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (!(guard[0] < limit)) {
+        if (i == 0) withheld[0] += 1;
+        return;
+    }
+    if (i >= n) return;
+    const float lr = lr_dev[0];
+    const float d = fmaf(wd, p[i], g[i]);
+    const float b = buf[i] * momentum + d;
+    buf[i] = b;
+    p[i] = fmaf(-lr, b, p[i]);
+}
+
 extern "C" {
 
 int az_loss_fwd_bwd(int32_t num_actions, const float* logits, const float* v_hat, const float* target, const float* z,
@@ -122,6 +141,18 @@ int az_sgd_momentum_lr_dev(float* params, const float* grads, float* momentum_bu
     hipLaunchKernelGGL(k_sgd_lr_dev, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grads,
                        momentum_buf, (long)n, lr_dev, momentum, weight_decay);
     AZ_LAUNCH_CHECK("k_sgd_lr_dev");
+    return 0;
+}
+
+int az_sgd_momentum_guarded(float* params, const float* grads, float* momentum_buf, int64_t n, const float* lr_dev,
+                            float momentum, float weight_decay, const float* guard_dev, float guard_limit,
+                            int32_t* withheld_dev, void* stream) {
+    if (n < 0 || !lr_dev || !guard_dev || !withheld_dev || (n && (!params || !grads || !momentum_buf)))
+        return az_fail("az_sgd_momentum_guarded: null pointer");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_sgd_guarded, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grads,
+                       momentum_buf, (long)n, lr_dev, momentum, weight_decay, guard_dev, guard_limit, withheld_dev);
+    AZ_LAUNCH_CHECK("k_sgd_guarded");
     return 0;
 }
 

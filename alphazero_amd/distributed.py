@@ -78,7 +78,7 @@ def gather_records_device(records, head, dst=0, group=None):
     """Finished games of every rank collected on `dst` without leaving device memory:
     (records, head) as returned by SelfPlayEngine.take_finished_device on each rank ->
     (uint8 tensor [sum n, RECORD_BYTES] on `dst` in rank order -- an empty tensor elsewhere --, OR of
-    the ranks' error bits).  One all_gather of the 8-byte heads, whose host read is the only
+    the ranks' error bits, this rank's own count).  One all_gather of the 8-byte heads, whose host read is the only
     synchronisation, then one gather of the records padded to the largest count.  Replaces
     ReplayBufferDataset.add_game across processes (alphazero/replay_buffer.py:165-167, 28-47)."""
     world = dist.get_world_size(group)
@@ -97,16 +97,22 @@ def gather_records_device(records, head, dst=0, group=None):
     cap = max(counts)
     empty = records[:0]
     if cap == 0:
-        return empty, flags
-    send = records[:cap]
+        return empty, flags, counts[rank]
+    if records.shape[0] >= cap:
+        send = records[:cap]
+    else:
+        # a rank whose engine (and so its record buffer) is smaller than another rank's largest hand-over: every
+        # rank must send `cap` rows, so the short buffer is padded (its own count is below its own size)
+        send = torch.zeros(cap, records.shape[1], dtype=records.dtype, device=records.device)
+        send[:records.shape[0]] = records
     if send.device != head.device:
         send = send.to(head.device)
     if rank == dst:
         bufs = [torch.empty_like(send) for _ in range(world)]
         dist.gather(send, bufs, dst=dst, group=group)
-        return torch.cat([bufs[r][:counts[r]] for r in range(world)]).to(home), flags
+        return torch.cat([bufs[r][:counts[r]] for r in range(world)]).to(home), flags, counts[rank]
     dist.gather(send, None, dst=dst, group=group)
-    return empty, flags
+    return empty, flags, counts[rank]
 
 
 def records_to_bytes(records):

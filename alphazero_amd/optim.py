@@ -41,6 +41,7 @@ class FlatSGD(torch.optim.Optimizer):
                 p.grad = self.flat_g[off:off + k].view_as(p)
                 off += k
         self._steps = 0
+        self.withheld = torch.zeros(1, dtype=torch.int32, device=dev)   # recorded steps whose update the guard refused
         self._lr_dev = None                                # learning rate in device memory, for recorded steps
 
     def zero_grad(self, set_to_none=False):
@@ -67,15 +68,25 @@ class FlatSGD(torch.optim.Optimizer):
             self._lr_host = lr
 
     @torch.no_grad()
-    def step_recorded(self):
+    def step_recorded(self, guard=None, guard_limit=1e-6):
         """The same update with the learning rate read from device memory at run time (az_sgd_momentum_lr_dev):
         the launch can be captured in a HIP graph and replayed while a scheduler changes the rate.  Call
-        set_recorded_lr() (outside the capture) before every run."""
+        set_recorded_lr() (outside the capture) before every run.
+        guard: a one-element float32 device tensor written earlier in the same recorded sequence; the update is
+        applied only while guard < guard_limit (az_sgd_momentum_guarded), otherwise nothing changes and
+        self.withheld (device int32[1]) counts the step."""
         g = self.param_groups[0]
         assert self._lr_dev is not None, 'set_recorded_lr() first'
         with torch.cuda.device(self.device):
             st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-            _lib.check(self.lib.az_sgd_momentum_lr_dev(_lib.ptr(self.flat_p), _lib.ptr(self.flat_g), _lib.ptr(self.flat_m),
-                                                       self.flat_p.numel(), _lib.ptr(self._lr_dev), float(g['momentum']),
-                                                       float(g['weight_decay']), st))
+            if guard is None:
+                _lib.check(self.lib.az_sgd_momentum_lr_dev(_lib.ptr(self.flat_p), _lib.ptr(self.flat_g), _lib.ptr(self.flat_m),
+                                                           self.flat_p.numel(), _lib.ptr(self._lr_dev), float(g['momentum']),
+                                                           float(g['weight_decay']), st))
+            else:
+                assert guard.dtype == torch.float32 and guard.numel() == 1 and guard.device == self.device
+                _lib.check(self.lib.az_sgd_momentum_guarded(_lib.ptr(self.flat_p), _lib.ptr(self.flat_g), _lib.ptr(self.flat_m),
+                                                            self.flat_p.numel(), _lib.ptr(self._lr_dev), float(g['momentum']),
+                                                            float(g['weight_decay']), _lib.ptr(guard), float(guard_limit),
+                                                            _lib.ptr(self.withheld), st))
         self._steps += 1

@@ -161,6 +161,22 @@ class SelfPlayWorker:
         self.games_finished += n
         return recs[:n].clone()
 
+    def take_finished_device(self):
+        """The engine's hand-over as it is -- (records uint8 [ring capacity, record size], head int32[2] =
+        {count, error bits}), both still on the device and not read here -- for callers that ship them to
+        another rank first (distributed.gather_records_device) and report what came of it with
+        `account_finished`."""
+        return self.engine.take_finished_device()
+
+    def account_finished(self, count, flags):
+        """Book-keeping for hand-overs whose head was read elsewhere: raises on engine error bits like the
+        collect_* methods, then counts the games."""
+        self.engine_flags = int(flags)
+        if flags:
+            raise _engine.AzError(f'engine error bits {flags}: 1 = node pool exhausted, 2 = finished games dropped, '
+                                  '8 = visit sum beyond the PUCT table, 16 = a one-launch move was abandoned by its watchdog')
+        self.games_finished += int(count)
+
     def refresh_model(self):
         """selfplay.py:16-22: pull the latest weights; version 0 means 'no model yet'."""
         self._version = int(self._model_server.latest(self._model))

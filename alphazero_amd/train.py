@@ -68,10 +68,9 @@ def synchronous_play_and_train(config, device, num_games=1024, num_steps=None, m
         elif multi:
             # records stay in device memory from the engine's ring to the trainer's window
             from .distributed import gather_records_device
-            recs, head = worker.engine.take_finished_device()
-            recs, flags = gather_records_device(recs, head, dst=trainer_rank)
-            if flags:
-                raise RuntimeError(f'engine error bits {flags} on some rank')
+            recs, head = worker.take_finished_device()
+            recs, flags, mine = gather_records_device(recs, head, dst=trainer_rank)
+            worker.account_finished(mine, flags)           # raises on any rank's error bits, counts this rank's games
             if trainer is not None:
                 window.add_records_device(recs)
         elif pipelined:

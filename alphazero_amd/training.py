@@ -144,7 +144,9 @@ class TrainingWorker:
             self._optimizer.zero_grad()
             total = policy_loss + value_loss
             total.backward()
-            self._optimizer.step_recorded()
+            # the update itself is conditional on the loss kernel's check of the targets, on the device: a batch
+            # that fails it changes no weight (the reference asserts before optimizer.step(), loss.py:58-59)
+            self._optimizer.step_recorded(guard=getattr(self._loss, 'target_deviation', None))
         self._graph = graph
         self._g_out = (policy_loss.detach(), value_loss.detach(), total.detach())
         return graph
@@ -162,8 +164,11 @@ class TrainingWorker:
         self._iter += 1
         self._model_server.update(self._model, it + 1)
         if self._writer is not None or it % self.CHECK_EVERY == 0:
-            dev = getattr(self._loss, 'target_deviation', None)
-            assert dev is None or float(dev) < 1e-6, 'Target policy must be a valid distribution'
+            # Read back every CHECK_EVERY-th step (every step with a writer).  A batch that failed the check in
+            # between had its update withheld by the recorded step itself (the weights published for it are the
+            # previous ones), so nothing wrong was ever applied or handed out; the assertion just comes late.
+            withheld = int(self._optimizer.withheld)
+            assert withheld == 0, f'Target policy must be a valid distribution ({withheld} update(s) withheld)'
         if self._writer is not None:
             policy_loss, value_loss, total = self._g_out
             self._writer.add_scalar('loss/policy', policy_loss, it)

@@ -468,7 +468,7 @@ def main():
         # gathered on the replay rank over RCCL (replaces replay_buffer.py:28-47)
         if multi:
             recs, head = eng.take_finished_device()
-            got, flags = gather_records_device(recs, head, dst=0)
+            got, flags, _ = gather_records_device(recs, head, dst=0)
             assert flags == 0 or args.allow_pool_errors, f'engine error bits {flags}'
             finished_on_dst[0] += int(got.shape[0])
         else:

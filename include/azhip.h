@@ -343,6 +343,16 @@ int  az_sgd_momentum(float* params, const float* grads, float* momentum_buf, int
 int  az_sgd_momentum_lr_dev(float* params, const float* grads, float* momentum_buf, int64_t n, const float* lr_dev,
                             float momentum, float weight_decay, void* stream);
 
+/* az_sgd_momentum_lr_dev behind a check that is evaluated on the device: the update (parameters and momentum) is
+ * applied only when guard_dev[0] < guard_limit; otherwise nothing is written and withheld_dev[0] (DEVICE int32) is
+ * incremented.  For recorded steps, where the host cannot look at the batch between the loss and the update: with
+ * guard_dev = out3 + 2 of az_loss_fwd_bwd and guard_limit = 1e-6 a batch that fails the reference's assertion
+ * "Target policy must be a valid distribution" (alphazero/loss.py:58-59) changes no weight, as in the reference,
+ * where the assertion fires before optimizer.step() (training.py:59-71).                                       */
+int  az_sgd_momentum_guarded(float* params, const float* grads, float* momentum_buf, int64_t n, const float* lr_dev,
+                             float momentum, float weight_decay, const float* guard_dev, float guard_limit,
+                             int32_t* withheld_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -89,16 +89,18 @@ def _worker(rank, world, port, out_dir):
         r = [x for x in got if x.uid == 1002][0]
         assert r.history[3] == 4 and r.visits[5][6] == 156 and r.model_version == 5
     # --- the device-resident forms, on CPU tensors here: records as a fixed-capacity tensor + {count, flags}
-    for counts, flag in (((3, 0), 0), ((2, 5), 2), ((0, 0), 0)):
+    # (caps: the ranks' buffers differ in size in the last case -- engines of different sizes -- and rank 0's is
+    # shorter than rank 1's count: it must be padded, not sent short)
+    for counts, flag, caps in (((3, 0), 0, (12, 12)), ((2, 5), 2, (12, 12)), ((0, 0), 0, (12, 12)), ((1, 9), 0, (4, 20))):
         n = counts[rank]
-        cap = 12
+        cap = caps[rank]
         buf = torch.zeros(cap, D.RECORD_BYTES, dtype=torch.uint8)
         if n:
             buf[:n] = torch.from_numpy(D.records_to_bytes(_fake_records(rank, n)))
         buf[n:] = 0xEE                                            # stale tail of the ring copy must not travel
         head = torch.tensor([n, flag if rank == 1 else 0], dtype=torch.int32)
-        got, flags = D.gather_records_device(buf, head, dst=0)
-        assert flags == flag
+        got, flags, mine = D.gather_records_device(buf, head, dst=0)
+        assert flags == flag and mine == n
         if rank == 0:
             assert got.shape == (sum(counts), D.RECORD_BYTES)
             uids = [r.uid for r in D.bytes_to_records(got.numpy())]

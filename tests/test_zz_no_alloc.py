@@ -61,3 +61,60 @@ def test_static_entry_point_rejects_oversized_engines():
     with pytest.raises(AzError, match='16384'):
         eng.move_fused_static(net)
     eng.close()
+
+
+def test_static_entry_point_allocates_nothing_and_can_be_captured():
+    """What the entry point exists for.  (1) Free device memory is the same before and after a call (after one
+    warm-up call, so that lazily loaded code objects are in place).  (2) The call can be recorded in a HIP graph
+    -- where an allocation, a memset on another stream or a synchronisation would fail the capture -- and the
+    replayed launch builds the same trees as a direct az_c4_move_fused on an identical engine."""
+    from alphazero_amd import engine as E
+    from alphazero_amd.models import AlphaZeroC4
+    from alphazero_amd.net import FusedC4Net
+    torch.manual_seed(6)
+    net = FusedC4Net.from_module(AlphaZeroC4(6, 32).eval().cuda(), 'cuda')
+    G, S = 300, 30
+
+    def prepared(seed):
+        eng = E.SelfPlayEngine(E._lib.GAME_C4, G, S, exploration_depth=4, reuse_search_tree=True, seed=seed, device=0)
+        bb, info = eng.begin_move()
+        p, _ = net(bb, info)
+        eng.apply_root(p)
+        return eng
+
+    # (1) no allocation
+    eng = prepared(41)
+    eng.move_fused_static(net)                                 # warm-up
+    eng.choose_and_advance()
+    bb, info = eng.begin_move()
+    p, _ = net(bb, info)
+    eng.apply_root(p)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    eng.move_fused_static(net)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 == free1
+    eng.close()
+
+    # (2) under graph capture
+    want_eng, got_eng = prepared(42), prepared(42)
+    want_eng.move_fused(net)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            got_eng.move_fused_static(net)
+    torch.cuda.synchronize()
+    assert got_eng.stats()['sims'] == 0                         # recording runs nothing
+    graph.replay()
+    torch.cuda.synchronize()
+    a0, _, v0, _ = want_eng.choose_and_advance()
+    a1, _, v1, _ = got_eng.choose_and_advance()
+    assert torch.equal(a0, a1) and torch.equal(v0, v1)
+    assert v1.sum(1).min().item() >= S
+    for e in (want_eng, got_eng):
+        e.drain_finished()
+        assert e.error_flags() == 0
+        e.close()
