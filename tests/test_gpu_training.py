@@ -174,3 +174,68 @@ def test_recorded_training_step_equals_the_eager_one():
     assert any(r[0] == 'optim/learning_rate' and abs(r[1] - 0.01) < 1e-9 for r in rows_b)      # the schedule stepped
     for k in sd_a:
         assert torch.allclose(sd_a[k].float(), sd_b[k].float(), rtol=1e-5, atol=1e-6), (k, (sd_a[k].float() - sd_b[k].float()).abs().max())
+
+
+def test_recorded_step_withholds_the_update_of_a_bad_batch():
+    """The reference asserts 'Target policy must be a valid distribution' before optimizer.step()
+    (alphazero/loss.py:58-59, training.py:59-71): a bad batch never changes a weight.  The recorded step cannot
+    read the check back before its own update, so the update kernel is guarded on the device
+    (az_sgd_momentum_guarded): with corrupted targets in the window nothing changes and the withheld counter runs,
+    and the host's periodic read-back raises."""
+    from alphazero_amd import engine as E
+    from alphazero_amd.config import AlphaZeroConfig
+    from alphazero_amd.games import ConnectFour
+    from alphazero_amd.replay_buffer import DeviceReplayWindow
+    from alphazero_amd.training import TrainingWorker
+    cfg = AlphaZeroConfig(conf={
+        'game': {'module': 'alphazero.games.connectfour', 'name': 'ConnectFour'},
+        'model': {'module': 'alphazero.games.connectfour', 'name': 'AlphaZeroC4',
+                  'kwargs': {'num_blocks': 1, 'channels_per_block': 8}},
+        'loss': {'module': 'alphazero.loss', 'name': 'AlphaZeroLoss'},
+        'training': {'num_steps': 100, 'batch_size': 16, 'lr': 0.1, 'momentum': 0.9, 'weight_decay': 1e-4,
+                     'lr_schedule_gamma': 0.1, 'lr_schedule': [50]}})
+    dev = torch.device('cuda:0')
+    eng = E.SelfPlayEngine(E._lib.GAME_C4, 128, 8, exploration_depth=4, reuse_search_tree=True, seed=9, device=0)
+    window = DeviceReplayWindow(ConnectFour, 2048, dev)
+    while len(window) < 256:
+        eng.begin_move_uniform(); eng.run_sims_uniform(8); eng.choose_and_advance()
+        window.add_records(eng.drain_finished_bytes())
+
+    class Server:
+        def update(self, model, version):
+            pass
+    torch.manual_seed(3)
+    tw = TrainingWorker(cfg, Server(), window, None, dev, record_step=True)
+    tw.CHECK_EVERY = 4
+    for _ in range(5):                                         # three eager steps, then the recorded one twice
+        tw.process_batch()
+    assert tw._graph is not None and int(tw._optimizer.withheld) == 0
+    before = tw._optimizer.flat_p.clone()
+    window.p.mul_(1.5)                                         # every target row now sums to 1.5
+    raised = False
+    for _ in range(4):
+        try:
+            tw.process_batch()
+        except AssertionError as e:
+            assert 'valid distribution' in str(e)
+            raised = True
+            break
+    assert raised
+    assert int(tw._optimizer.withheld) >= 1
+    assert torch.equal(tw._optimizer.flat_p, before)           # not one weight moved
+    window.p.div_(1.5)
+
+    # the guarded kernel against the plain one on a passing check
+    from alphazero_amd.optim import FlatSGD
+    torch.manual_seed(4)
+    a = [torch.nn.Parameter(torch.randn(300, device=dev)), torch.nn.Parameter(torch.randn(7, 5, device=dev))]
+    b = [torch.nn.Parameter(t.detach().clone()) for t in a]
+    oa, ob = FlatSGD(a, 0.05, 0.9, 1e-4), FlatSGD(b, 0.05, 0.9, 1e-4)
+    ok = torch.zeros(1, device=dev)
+    for step in range(3):
+        g = torch.randn(oa.flat_g.numel(), device=dev)
+        oa.flat_g.copy_(g); ob.flat_g.copy_(g)
+        oa.set_recorded_lr(); ob.set_recorded_lr()
+        oa.step_recorded()
+        ob.step_recorded(guard=ok)
+    assert torch.equal(oa.flat_p, ob.flat_p) and int(ob.withheld) == 0
