@@ -78,6 +78,8 @@ SIGNATURES = {
     'az_c4net_blob_bytes': (C.c_int, []),
     'az_c4net_bf16_forward': (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P, _P, _P]),
     'az_c4net_f32_blob_floats': (C.c_int, []),
+    'az_c4net_hx_blob_bytes': (C.c_int, []),
+    'az_c4net_hx_forward': (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P, _P, _P]),
     'az_examples_from_records': (C.c_int, [C.c_int32, _P, C.c_int32, _P, C.c_int32, _P, _P, _P, _P, _P, _P]),
     'az_c4net128_blob_bytes': (C.c_int, []),
     'az_c4net128_workspace_bytes': (C.c_long, [C.c_int32]),

@@ -271,6 +271,102 @@ class FusedC4NetF32:
         return self._p, self._v
 
 
+HX_SCALE = 2048.0     # the low operand half is carried times 2^11 (csrc/az_net_hx_dev.h)
+
+
+def _frags16_hx(mat):
+    """[..., 16 rows, 32 k] float64 -> fp16 fragment bytes [..., 2 (h, l), 64, 8] (uint8 tensor): each weight
+    (rounded once to fp32) as h = fp16(w) and l = fp16((w - h) * 2048)."""
+    lead = mat.shape[:-2]
+    flat = mat.reshape(-1, 16 * 32)[:, _frag16_index(mat.device)].float()          # [n][512]
+    if not bool(torch.all(flat.abs() < 6.0e4)):
+        raise ValueError('fp16-pair kernel: a folded weight lies beyond the fp16 range')
+    h = flat.to(torch.float16)
+    l = ((flat - h.float()) * HX_SCALE).to(torch.float16)
+    both = torch.stack([h, l], dim=1)                                             # [n][2][512]
+    return both.reshape(*lead, 2 * 512).contiguous().view(torch.uint8).reshape(-1)
+
+
+def _trunk_frags_hx(w32):
+    """[..., 32 out channels, 32 k] -> fragments [..., 2 channel halves, 2 (h, l), 64, 8] (rows as _trunk_frags)."""
+    rows = _half_rows(w32.device)
+    return _frags16_hx(w32[..., rows, :])
+
+
+def pack_c4_blob_hx(model):
+    """AlphaZeroC4 module -> uint8 tensor in the layout of csrc/az_net_hx_dev.h (BN folded in float64, weights
+    rounded once to float32, trunk weights then split into fp16 pairs)."""
+    C_ = model.block_channels
+    if C_ > CMAX or tuple(model.shape_in) != (2, 6, 7):
+        raise ValueError('fp16-pair kernel: Connect Four nets with up to 32 trunk channels')
+    dev = model._cbr[0].weight.device
+    z = lambda *shape: torch.zeros(*shape, dtype=torch.float64, device=dev)
+    parts = []
+    with torch.no_grad():
+        bias = z(3, 32)
+        w, b = _fold_bn(model._cbr[0].weight, model._cbr[1])
+        stem = z(32, 32)
+        for kx in range(3):
+            for plane in range(2):
+                for ky in range(3):
+                    stem[:C_, 9 * kx + 3 * plane + ky] = w[:, plane, ky, kx]
+        parts.append(_trunk_frags_hx(stem))
+        bias[0, :C_] = b
+        if len(model._tower):
+            blk = model._tower[0]
+            for i, (cv, bn) in enumerate(((blk._c1, blk._bn1), (blk._c2, blk._bn2))):
+                w, b = _fold_bn(cv.weight, bn)
+                parts.append(_trunk_frags_hx(_conv_taps(w)))         # [9 taps][2 halves][h, l][64][8]
+                bias[1 + i, :C_] = b
+        else:
+            parts.append(torch.zeros(2 * 9 * 4 * 1024, dtype=torch.uint8, device=dev))
+        ident = _trunk_frags_hx(torch.eye(32, dtype=torch.float64, device=dev)).reshape(2, 2, 1024)
+        parts.append(ident[:, 0].reshape(-1))                         # the identity has no low half
+        ph, vh = model._policy_head, model._value_head
+        wpol, bpol = _fold_bn(ph._cbr[0].weight, ph._cbr[1], ph._cbr[0].bias)
+        wval, bval = _fold_bn(vh._cbr[0].weight, vh._cbr[1])
+        mat = z(16, 32)
+        mat[0:2, :C_] = wpol[:, :, 0, 0]
+        mat[2, :C_] = wval[0, :, 0, 0]
+        parts.append(_frags16_hx(mat))
+        parts.append(_f32_bytes(torch.cat([bias.reshape(-1), bpol[:2], bval[:1], vh._fc[2].bias.double().reshape(1)])))
+        parts.append(_f32_bytes(ph._fc.bias, 64))
+        parts.append(_f32_bytes(vh._fc[0].bias))
+        parts.append(_f32_bytes(vh._fc[2].weight))
+        parts.append(_f32_bytes(vh._fc[0].weight.t().reshape(42, 64, 4)))      # [cell][lane][u] = W1[4 lane + u][cell]
+        parts.append(_f32_bytes(ph._fc.weight))                                # [42 cells][84]
+        blob = torch.cat(parts)
+    assert blob.numel() == _lib.load().az_c4net_hx_blob_bytes(), (blob.numel(), _lib.load().az_c4net_hx_blob_bytes())
+    return blob
+
+
+class FusedC4NetHX:
+    """fp32-grade evaluator on the fp16 matrix cores (csrc/az_net_hx.hip): net(leaf_bb, leaf_info) -> (p, v),
+    within 1e-5 relative of the fp32 torch module; with leaf_info only the rows that need the network are
+    evaluated and written.  `blob` also feeds SelfPlayEngine.move_fused(..., precision='hx')."""
+
+    def __init__(self, model, device=None):
+        self.lib = _lib.load()
+        self.device = _device(device if device is not None else next(model.parameters()).device)
+        self.num_blocks = model.num_blocks
+        self.blob = pack_c4_blob_hx(model).to(self.device)
+        assert self.blob.data_ptr() % 16 == 0
+        self._p = self._v = None
+
+    def load_module(self, model):
+        self.blob.copy_(pack_c4_blob_hx(model))
+        self.num_blocks = model.num_blocks
+
+    def __call__(self, leaf_bb, leaf_info=None):
+        n = leaf_bb.shape[0]
+        if self._p is None or self._p.shape[0] != n:
+            self._p = torch.empty(n, 7, dtype=torch.float32, device=self.device)
+            self._v = torch.empty(n, dtype=torch.float32, device=self.device)
+        _launch(self.device, lambda st: self.lib.az_c4net_hx_forward(ptr(self.blob), self.num_blocks, ptr(leaf_bb), ptr(leaf_info),
+                                           n, ptr(self._p), ptr(self._v), st))
+        return self._p, self._v
+
+
 def pack_c4_blob_128(model):
     """AlphaZeroC4 with 128 trunk channels -> uint8 blob in the layout of csrc/az_net128.hip."""
     if model.block_channels != 128 or tuple(model.shape_in) != (2, 6, 7):

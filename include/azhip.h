@@ -261,6 +261,16 @@ int  az_c4net_f32_blob_floats(void);
 int  az_c4net_f32_forward(const float* blob, int32_t num_blocks, const uint64_t* leaf_bb, int32_t n,
                           float* p, float* v, void* stream);
 
+/* Same network at fp32 grade on the fp16 matrix cores: every operand of the trunk is a pair of fp16 numbers
+ * (leading and following 11 bits), every product three v_mfma_f32_16x16x32_f16 with fp32 accumulation, the fully
+ * connected heads in fp32 (csrc/az_net_hx_dev.h).  Outputs within 1e-5 relative of the fp32 torch statement, like
+ * az_c4net_f32_forward, at several times its rate; a leaf's (p, v) do not depend on the batch it is in.  blob =
+ * DEVICE buffer of az_c4net_hx_blob_bytes() bytes (alphazero_amd/net.py pack_c4_blob_hx); leaf_info as for
+ * az_c4net_bf16_forward (NULL = every leaf).  Activations saturate at 65504.  Replaces the same reference lines. */
+int  az_c4net_hx_blob_bytes(void);
+int  az_c4net_hx_forward(const uint8_t* blob, int32_t num_blocks, const uint64_t* leaf_bb,
+                         const int32_t* leaf_info, int32_t n, float* p, float* v, void* stream);
+
 /* 128-channel network (e.g. 10x128) on bf16 MFMA: stem, residual tower with LDS-resident
  * activations, heads -- three launches, plus one that lists the leaves to evaluate when leaf_info is
  * given (kinds EVAL / ROOT, as az_c4net_bf16_forward; NULL = every leaf).  workspace = DEVICE buffer
