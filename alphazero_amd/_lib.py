@@ -87,6 +87,7 @@ SIGNATURES = {
     'az_c4net_f32_forward': (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P, _P]),
     'az_c4_move_fused_max_games': (C.c_int, [_P]),
     'az_c4_move_fused': (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, _P]),
+    'az_c4_move_fused_hx': (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, _P]),
     'az_c4_move_fused_limit_workgroups': (C.c_int, [_P, C.c_int32]),
     'az_c4_move_fused_counters': (C.c_int, [_P, C.POINTER(C.c_uint64), _P]),
     'az_c4_move_fused_static': (C.c_int, [_P, _P, C.c_int32, _P]),

@@ -33,6 +33,7 @@
 #include "../../include/azhip.h"
 #include "az_games.h"
 #include "az_net_dev.h"
+#include "az_net_hx_dev.h"
 #include "az_host.h"
 
 #define WAVES_PER_BLOCK 4
@@ -949,6 +950,10 @@ __global__ void __launch_bounds__(1024) k_fused_balance(Dev E, int gpw, int grid
 #define FX_END (FX_OWN + FUSED_WAVES * FX_OWN_BYTES)
 #endif
 #define FUSED_LDS_BYTES (OFF_BIAS + FX_END)
+// the fp16-pair form (az_net_hx_dev.h): its own weights in front, the same hand-off layout behind them, then one
+// strip of head planes per worker
+#define FX_HX_STRIPS FX_END
+#define FUSED_LDS_BYTES_HX (HX_W_BYTES + FX_HX_STRIPS + FUSED_WAVES * HX_STRIP_BYTES)
 // the engine's 512-byte counter block (E.ring_count, uint32 words): 0 finished games in the ring, 1 error bits,
 // 8..15 four 64-bit counters of this kernel (az_c4_move_fused_counters), 16..23 tuning builds, 64.. az_generic_select
 #define FUSED_COUNTER_WORD 8
@@ -1009,27 +1014,36 @@ __device__ unsigned long long g_done_dbg[8];     // cycles from the start until 
 #ifndef FUSED_MIN_WAVES       // waves per SIMD the register budget is cut for; diagnostic builds raise it to make the
 #define FUSED_MIN_WAVES (FUSED_WAVES / 4)     // kernel spill (3: 168 registers, 4: 128)
 #endif
+// HX: the network at fp32 grade (operands as fp16 pairs, az_net_hx_dev.h; blob = pack_c4_blob_hx): every leaf is a
+// one-board task whose worker also runs its heads -- the policy of a workgroup with few games, for any number of
+// games.  Everything else (queues, search steps, hand-offs) is the same code.
+template <bool HX>
 __global__ void __launch_bounds__(FUSED_THREADS, FUSED_MIN_WAVES)
 k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, int32_t* leaf_info, float* p,
                 float* v, int num_sims, int gpw) {
     constexpr int GS = 8;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t* wlds = lds;
-    uint8_t* scr = lds + OFF_BIAS;
+    uint8_t* scr = lds + (HX ? HX_W_BYTES : OFF_BIAS);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     {
         uint4* z = reinterpret_cast<uint4*>(scr);
         for (int i = tid; i < FX_END / 16; i += FUSED_THREADS) z[i] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
-    if (tid < 99) reinterpret_cast<float*>(scr + S_BIAS)[tid] = reinterpret_cast<const float*>(blob + OFF_BIAS)[tid];
-    if (tid == 99) reinterpret_cast<float*>(scr + S_BIAS)[99] = reinterpret_cast<const float*>(blob + OFF_B2)[0];
-    if (tid < 256) {
-        reinterpret_cast<float*>(scr + S_B1)[tid] = reinterpret_cast<const float*>(blob + OFF_B1)[tid];
-        reinterpret_cast<float*>(scr + S_W2)[tid] = reinterpret_cast<const float*>(blob + OFF_W2)[tid];
+    if constexpr (HX) {
+        if (tid < 100) reinterpret_cast<float*>(scr + S_BIAS)[tid] = reinterpret_cast<const float*>(blob + HX_OFF_BIAS)[tid];
+        hx_load_weights(blob, wlds, tid, FUSED_THREADS);       // once per move
+    } else {
+        if (tid < 99) reinterpret_cast<float*>(scr + S_BIAS)[tid] = reinterpret_cast<const float*>(blob + OFF_BIAS)[tid];
+        if (tid == 99) reinterpret_cast<float*>(scr + S_BIAS)[99] = reinterpret_cast<const float*>(blob + OFF_B2)[0];
+        if (tid < 256) {
+            reinterpret_cast<float*>(scr + S_B1)[tid] = reinterpret_cast<const float*>(blob + OFF_B1)[tid];
+            reinterpret_cast<float*>(scr + S_W2)[tid] = reinterpret_cast<const float*>(blob + OFF_W2)[tid];
+        }
+        if (tid < 64) reinterpret_cast<float*>(scr + S_BP)[tid] = reinterpret_cast<const float*>(blob + OFF_BP)[tid];
+        if (tid < NTHREADS) load_weights(blob, wlds, tid);         // once per move
     }
-    if (tid < 64) reinterpret_cast<float*>(scr + S_BP)[tid] = reinterpret_cast<const float*>(blob + OFF_BP)[tid];
-    if (tid < NTHREADS) load_weights(blob, wlds, tid);         // once per move
 
     // LDS words of the hand-offs (all zero now): the task-list area holds the games' select counts, the value
     // partial-sum area the two rings
@@ -1111,7 +1125,7 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
 #else
 #define TICK(acc) do { } while (0)
 #endif
-    const bool few_games = gpw <= FUSED_FEW_GAMES;
+    const bool few_games = HX || gpw <= FUSED_FEW_GAMES;
     // what this worker did (wave-uniform counts, added to the engine's counters when it leaves): two-board tasks,
     // one-board tasks, head batches, boards in head batches
     uint32_t did_pair = 0, did_single = 0, did_hbatch = 0, did_hboards = 0;
@@ -1143,6 +1157,21 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
             if (!AZ_IDX_OK(E, g0 >= 0 && g0 < 64 && g1 >= -1 && g1 < 64, 9, (g0 << 8) | (g1 & 255))) break;
             __bf16* hp0 = reinterpret_cast<__bf16*>(planes + g0 * PLANE_SLOT);
             const int tl = phase_lane(lane);
+            if constexpr (HX) {
+                float* strip = reinterpret_cast<float*>(scr + FX_HX_STRIPS + wave_u * HX_STRIP_BYTES);
+                hx_trunk_task(wlds, sbias, num_blocks, lbb + 2 * g0, strip, tl);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");          // the strip, before this wave reads it back
+                const int g = gmap[g0];
+                __builtin_amdgcn_s_setprio(3);
+                hx_heads_own(blob, sbias, strip, lbb + 2 * g0, p + (size_t)g * 7, v + g, tl);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // (p, v), before the game is queued
+#ifdef AZ_EXP_TIMING
+                if (tl == 0) tstamp[g0] = (int)clock64();
+#endif
+                if (tl == 0) ring_push(readyq, ctr + FC_READY_TAIL, g0);
+                ++did_hbatch; ++did_hboards;
+            } else {
             if (g1 >= 0) {
                 const int g_mine = (tl & 8) ? g1 : g0;
                 __bf16* hp1 = reinterpret_cast<__bf16*>(planes + g1 * PLANE_SLOT);
@@ -1179,6 +1208,7 @@ k_c4_move_fused(Dev E, const uint8_t* blob, int num_blocks, uint64_t* leaf_bb, i
             } else if (lane == 0) {
                 ring_push(planeq, ctr + FC_PLANES_TAIL, g0);
                 if (g1 >= 0) ring_push(planeq, ctr + FC_PLANES_TAIL, g1);
+            }
             }
             TICK(t_task);
             if (g1 >= 0) ++did_pair; else ++did_single;
@@ -1666,11 +1696,13 @@ static uint8_t* g_scratch_ptr[MAX_DEVICES];                         // device ad
 static_assert(FS_OFF_INFO % 256 == 0 && FS_OFF_P % 256 == 0 && FS_OFF_V % 256 == 0, "scratch sub-arrays stay aligned");
 
 static std::atomic<unsigned long long> g_fused_attr_done{0};        // bit d = k_c4_move_fused may use its LDS on device d
+static std::atomic<unsigned long long> g_fused_hx_attr_done{0};     // the same for its fp16-pair form
 
 // with device `dev` current: look the array's address up once per device, and give the kernel its dynamic-LDS
 // attribute here, so that az_c4_move_fused_static itself is nothing but a launch
 static int scratch_setup(int dev) {
-    if (int rc = az_set_kernel_lds(reinterpret_cast<const void*>(k_c4_move_fused), FUSED_LDS_BYTES, g_fused_attr_done)) return rc;
+    if (int rc = az_set_kernel_lds(reinterpret_cast<const void*>(k_c4_move_fused<false>), FUSED_LDS_BYTES, g_fused_attr_done)) return rc;
+    if (int rc = az_set_kernel_lds(reinterpret_cast<const void*>(k_c4_move_fused<true>), FUSED_LDS_BYTES_HX, g_fused_hx_attr_done)) return rc;
     if (dev < 0 || dev >= MAX_DEVICES) return 0;                    // az_c4_move_fused_static refuses such a device
     if (g_scratch_ptr[dev]) return 0;
     void* ptr = nullptr;
@@ -1963,7 +1995,7 @@ static int fused_workgroups(const az_engine* e) {
     return (e->fused_wgs > 0 && e->fused_wgs < e->num_cus) ? e->fused_wgs : e->num_cus;
 }
 static int fused_launch(az_engine* e, const uint8_t* blob, int32_t num_blocks, uint64_t* leaf_bb, int32_t* leaf_info,
-                        float* p, float* v, hipStream_t st) {
+                        float* p, float* v, hipStream_t st, bool hx = false) {
     if (e->cfg.game != AZ_GAME_C4) return az_fail("az_c4_move_fused: Connect Four only");
     if (num_blocks < 0) return az_fail("az_c4_move_fused: num_blocks");
     if (e->d.S <= 0) return 0;
@@ -1972,11 +2004,16 @@ static int fused_launch(az_engine* e, const uint8_t* blob, int32_t num_blocks, u
     if (gpw > FUSED_MAX_GPW) return az_fail("az_c4_move_fused: more than 64 games per workgroup");
     const int grid = (e->d.G + gpw - 1) / gpw;
     // already done by az_engine_create on this device (a bitmap test, then nothing)
-    if (int rc = az_set_kernel_lds(reinterpret_cast<const void*>(k_c4_move_fused), FUSED_LDS_BYTES, g_fused_attr_done)) return rc;
+    if (int rc = az_set_kernel_lds(reinterpret_cast<const void*>(k_c4_move_fused<false>), FUSED_LDS_BYTES, g_fused_attr_done)) return rc;
+    if (int rc = az_set_kernel_lds(reinterpret_cast<const void*>(k_c4_move_fused<true>), FUSED_LDS_BYTES_HX, g_fused_hx_attr_done)) return rc;
     if (e->d.G > BALANCE_MAX_GAMES) return az_fail("az_c4_move_fused: more than 16384 games");
     hipLaunchKernelGGL(k_fused_balance, dim3(1), dim3(1024), 0, st, e->d, gpw, grid);
-    hipLaunchKernelGGL(k_c4_move_fused, dim3(grid), dim3(FUSED_THREADS), FUSED_LDS_BYTES, st, e->d, blob, (int)num_blocks, leaf_bb,
-                       leaf_info, p, v, (int)e->d.S, gpw);
+    if (hx)
+        hipLaunchKernelGGL(k_c4_move_fused<true>, dim3(grid), dim3(FUSED_THREADS), FUSED_LDS_BYTES_HX, st, e->d, blob, (int)num_blocks,
+                           leaf_bb, leaf_info, p, v, (int)e->d.S, gpw);
+    else
+        hipLaunchKernelGGL(k_c4_move_fused<false>, dim3(grid), dim3(FUSED_THREADS), FUSED_LDS_BYTES, st, e->d, blob, (int)num_blocks,
+                           leaf_bb, leaf_info, p, v, (int)e->d.S, gpw);
     AZ_LAUNCH_CHECK("k_c4_move_fused");
     return 0;
 }
@@ -2004,6 +2041,13 @@ int az_c4_move_fused(az_engine* e, const uint8_t* blob, int32_t num_blocks, uint
     if (!e || !blob || !leaf_bb || !leaf_info || !p || !v) return az_fail("null argument");
     ENGINE_SCOPE(e);
     return fused_launch(e, blob, num_blocks, leaf_bb, leaf_info, p, v, (hipStream_t)stream);
+}
+
+int az_c4_move_fused_hx(az_engine* e, const uint8_t* blob, int32_t num_blocks, uint64_t* leaf_bb, int32_t* leaf_info,
+                        float* p, float* v, void* stream) {
+    if (!e || !blob || !leaf_bb || !leaf_info || !p || !v) return az_fail("null argument");
+    ENGINE_SCOPE(e);
+    return fused_launch(e, blob, num_blocks, leaf_bb, leaf_info, p, v, (hipStream_t)stream, true);
 }
 
 int az_c4_move_fused_static(az_engine* e, const uint8_t* blob, int32_t num_blocks, void* stream) {

@@ -162,13 +162,16 @@ class SelfPlayEngine:
                 'head_boards': int(out[3])}
 
     def move_fused(self, net):
-        """All S simulations of the move in one launch with a FusedC4Net (after begin_move / apply_root)."""
+        """All S simulations of the move in one launch with a FusedC4Net or a FusedC4NetHX (after begin_move /
+        apply_root)."""
         if self._pv is None:
             self._pv = (torch.zeros(self.G, self.A, dtype=torch.float32, device=self.device),
                         torch.zeros(self.G, dtype=torch.float32, device=self.device))
         p, v = self._pv
-        check(self.lib.az_c4_move_fused(self.h, ptr(net.blob), int(net.num_blocks), ptr(self.leaf_bb),
-                                        ptr(self.leaf_info), ptr(p), ptr(v), self._stream()))
+        # a FusedC4NetHX (fp16-pair operands, fp32-grade outputs) goes to the kernel's form for that blob
+        fn = self.lib.az_c4_move_fused_hx if getattr(net, 'precision', 'bf16') == 'hx' else self.lib.az_c4_move_fused
+        check(fn(self.h, ptr(net.blob), int(net.num_blocks), ptr(self.leaf_bb), ptr(self.leaf_info), ptr(p), ptr(v),
+                 self._stream()))
 
     def move_fused_static(self, net):
         """move_fused through the entry point that allocates nothing and takes no staging buffers

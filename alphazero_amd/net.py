@@ -343,7 +343,8 @@ def pack_c4_blob_hx(model):
 class FusedC4NetHX:
     """fp32-grade evaluator on the fp16 matrix cores (csrc/az_net_hx.hip): net(leaf_bb, leaf_info) -> (p, v),
     within 1e-5 relative of the fp32 torch module; with leaf_info only the rows that need the network are
-    evaluated and written.  `blob` also feeds SelfPlayEngine.move_fused(..., precision='hx')."""
+    evaluated and written.  SelfPlayEngine.move_fused(net) runs the one-launch move kernel with these weights."""
+    precision = 'hx'
 
     def __init__(self, model, device=None):
         self.lib = _lib.load()

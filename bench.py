@@ -20,7 +20,7 @@ broadcast from rank 0 (when a network is in use) and the finished games' records
 on rank 0, both device to device.  Rank 0 prints one JSON line.
 
 At N = 1 the line also carries, measured after the timed region: `fp32_net` (the same loop with
-the fp32 parity network kernel), `agreement` (bf16 production path against the fp32 kernel in
+the fp32-grade network kernels), `agreement` (bf16 production path against the fp32-grade kernel in
 the loop on identical random streams), `config4_leaf_eval` (the 10x128 network on 16 384-leaf
 batches) and `cpu_baseline`.
 """
@@ -179,12 +179,12 @@ def latest_profile(name_suffix):
     return files[-1] if files else None
 
 
-def measure_agreement(dev, net_bf16, net_f32, S, games=256, moves=12, seed=77):
-    """The production path (bf16 network, one launch per move) against the fp32 parity kernel in the
-    stepwise loop (alphazero/mcts.py:94-107 evaluates in fp32), `games` Connect Four games from the empty
-    board on identical Dirichlet / sampling streams (same engine seed: the device RNG is a function of
-    seed, game and move).  A (game, move) pair is compared while the two runs have played the same
-    moves so far."""
+def measure_agreement(dev, side_a, side_b, S, note, games=256, moves=12, seed=77):
+    """Two evaluators in the same self-play (alphazero/mcts.py:94-107 evaluates in fp32): `games` Connect Four
+    games from the empty board on identical Dirichlet / sampling streams (same engine seed: the device RNG is
+    a function of seed, game and move).  A side is (network, one_launch): one_launch = all simulations of a
+    move in the one-launch kernel, else the stepwise loop.  A (game, move) pair is compared while the two runs
+    have played the same moves so far."""
     import numpy as np
     import torch
     from alphazero_amd import engine as E
@@ -195,12 +195,11 @@ def measure_agreement(dev, net_bf16, net_f32, S, games=256, moves=12, seed=77):
     l1_sum, l1_max = 0.0, 0.0
     for mv in range(moves):
         out = []
-        for k, eng in enumerate(engs):
-            net = net_bf16 if k == 0 else net_f32
+        for eng, (net, one_launch) in zip(engs, (side_a, side_b)):
             bb, info = eng.begin_move()
             p, _ = net(bb, info)
             eng.apply_root(p)
-            if k == 0:
+            if one_launch:
                 eng.move_fused(net)
             else:
                 bb, info = eng.select()
@@ -225,14 +224,13 @@ def measure_agreement(dev, net_bf16, net_f32, S, games=256, moves=12, seed=77):
             l1_max = max(l1_max, float(l1.max()))
         same &= a0 == a1
     for eng in engs:
+        assert eng.error_flags() == 0
         eng.close()
     return {'games': games, 'sims_per_move': S, 'moves_per_game': moves, 'positions_compared': compared,
             'moves_equal_frac': equal_moves / max(compared, 1),
             'visit_vectors_identical_frac': equal_visits / max(compared, 1),
             'mean_l1_pi': l1_sum / max(compared, 1), 'max_l1_pi': l1_max,
-            'games_identical_to_the_end': int(same.sum()),
-            'note': 'bf16 MFMA network in az_c4_move_fused vs az_c4net_f32_forward in the stepwise loop; same '
-                    'noise and sampling streams; pairs compared while both runs share the history'}
+            'games_identical_to_the_end': int(same.sum()), 'note': note}
 
 
 def config4_leaf_eval(dev, iters=10, n=16384):
@@ -617,8 +615,25 @@ def main():
                     out[name] = fn()
                 except Exception as e:                  # noqa: BLE001
                     out[name] = {'error': f'{type(e).__name__}: {e}'}
+            from alphazero_amd.net import FusedC4NetHX
+            hx = FusedC4NetHX(net, dev)
+
             def extra_fp32():
-                # (a) the same self-play loop with the fp32 parity kernel evaluating every leaf (stepwise calls)
+                # (a) the same self-play loop at the reference's own network precision (alphazero/mcts.py:94-107
+                # evaluates in fp32): the one-launch move kernel with the fp16-pair network (three MFMAs per product,
+                # outputs within 1e-5 of the fp32 module), and the stepwise loop with the fp32-MFMA kernel beside it
+                def hx_step():
+                    bb, info = eng.begin_move()
+                    p, _ = hx(bb, info)
+                    eng.apply_root(p)
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    eng.move_fused(hx)
+                    b.record()
+                    eng.choose_and_advance()
+                    eng.drain_finished_bytes()
+                    return a, b
+
                 def f32_step():
                     bb, info = eng.begin_move()
                     p, _ = f32(bb, info)
@@ -632,16 +647,62 @@ def main():
                             eng.expand_backup(p, v)
                     eng.choose_and_advance()
                     eng.drain_finished_bytes()
+                hx_step()
+                st_a = eng.stats()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                evs = [hx_step() for _ in range(4)]
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t1) / 4
+                st_b = eng.stats()
+                assert st_b['errors'] == 0 and st_b['sims'] - st_a['sims'] == 4 * G * S
+                launch_ms = sum(a.elapsed_time(b) for a, b in evs) / 4
+                leaves = (st_b['leaf_evals'] - st_a['leaf_evals']) / 4
+                tf = leaves * trunk_flops_per_leaf(blocks, ch) / (launch_ms * 1e-3) / 1e12
                 f32_step()
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                for _ in range(2):
-                    f32_step()
+                f32_step()
                 torch.cuda.synchronize()
-                dt = (time.perf_counter() - t1) / 2
-                return {'value': G / dt, 'unit': 'positions/s', 'ms_per_step': 1e3 * dt, 'steps': 2,
-                                   'kernel': 'k_c4net_f32 (v_mfma_f32_32x32x2_f32, every leaf) + k_sim_step_p per simulation',
-                                   'note': 'the configuration whose network outputs are within 1e-5 of the reference fp32 net'}
+                dt32 = time.perf_counter() - t1
+                return {'value': G / dt, 'unit': 'positions/s', 'sims_per_s': G * S / dt, 'ms_per_step': 1e3 * dt, 'steps': 4,
+                        'kernel': 'k_c4_move_fused<fp16 pairs> (az_c4_move_fused_hx: v_mfma_f32_16x16x32_f16, three per '
+                                  'product, f32 accumulate; heads in f32)',
+                        'roofline': {'bound': 'mfma', 'avg_launch_ms': launch_ms, 'leaves_per_launch': leaves,
+                                     'achieved': tf, 'unit': 'TFLOP/s (algorithmic, fp32-grade)',
+                                     'mfma_issued_tflops': 3 * tf, 'peak': BF16_PEAK_TFLOPS,
+                                     'frac': 3 * tf / BF16_PEAK_TFLOPS,
+                                     'note': 'frac = issued fp16 matrix work (3 MFMAs per product) / dense fp16 peak'},
+                        'stepwise_f32_mfma': {'value': G / dt32, 'unit': 'positions/s', 'ms_per_step': 1e3 * dt32, 'steps': 1,
+                                              'kernel': 'k_c4net_f32 (v_mfma_f32_32x32x2_f32, every leaf) + k_sim_step_p per simulation'},
+                        'note': 'network outputs of both kernels are within 1e-5 relative of the reference fp32 net'}
+
+            def extra_cache():
+                # (e) the evaluation cache (opt-in; the reference evaluates every leaf, alphazero/mcts.py:139-142): same
+                # moves and records bit for bit, 2^24 entries, the model version bumped every move (no reuse across moves)
+                eng.enable_eval_cache(24)
+                ver = [1000]
+
+                def c_step():
+                    ver[0] += 1
+                    eng.set_model_version(ver[0])
+                    one_step(False)
+                    eng.drain_finished_bytes()
+                c_step()
+                st_a, h_a = eng.stats(), eng.eval_cache_hits()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(4):
+                    c_step()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t1) / 4
+                st_b, h_b = eng.stats(), eng.eval_cache_hits()
+                eng.enable_eval_cache(0)
+                ev = st_b['leaf_evals'] - st_a['leaf_evals']
+                return {'value': G / dt, 'unit': 'positions/s', 'ms_per_step': 1e3 * dt, 'steps': 4, 'log2_entries': 24,
+                        'hit_rate': (h_b - h_a) / max(ev, 1),
+                        'note': 'az_eval_cache_enable: bit-identical moves and records (tests/test_gpu_cache.py); not part of '
+                                'the headline value, which evaluates every leaf like the reference'}
             def extra_config5():
                 # (d) BASELINE config 5 on one GPU: the training step on the device-resident replay window, alone
                 # and inside the self-play loop (one SGD step and one weight hand-over per move of all games, as the
@@ -711,9 +772,19 @@ def main():
                                                            're-pack of the weights for the self-play kernels'},
                     'window_states': len(window), 'note': 'one GPU; with N ranks the records are gathered on the trainer rank '
                                                           'and the packed weights broadcast (see config.exchange)'}
+            stepwise_now[0] = False
             extra('fp32_net', extra_fp32)
-            # (b) how often the bf16 production path changes a move or a visit vector
-            extra('agreement', lambda: measure_agreement(dev, fused, f32, S))
+            # (b) how often the bf16 production path changes a move or a visit vector against the fp32-grade network
+            # (both in the one-launch kernel), and how the two fp32-grade kernels compare with each other
+            extra('agreement', lambda: measure_agreement(
+                dev, (fused, True), (hx, True), S,
+                'bf16 MFMA network vs fp16-pair (fp32-grade) network, both in the one-launch move kernel; same noise and '
+                'sampling streams; pairs compared while both runs share the history'))
+            extra('agreement_fp32_kernels', lambda: measure_agreement(
+                dev, (hx, True), (f32, False), S,
+                'fp16-pair network in the one-launch kernel vs az_c4net_f32_forward (fp32 MFMA) in the stepwise loop: two '
+                'kernels that both hold 1e-5 against the fp32 module, different summation orders', games=128, moves=8))
+            extra('eval_cache', extra_cache)
             # (c) BASELINE configs 2 and 4
             extra('config2_selfplay', lambda: config2_selfplay(dev, fused))
             extra('config4_leaf_eval', lambda: config4_leaf_eval(dev))

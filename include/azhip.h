@@ -295,6 +295,13 @@ int  az_c4net128_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uin
  * when enabled.  Results are bit-identical to the stepwise loop with az_c4net_bf16_forward.          */
 int  az_c4_move_fused(az_engine* e, const uint8_t* blob, int32_t num_blocks, uint64_t* leaf_bb,
                       int32_t* leaf_info, float* p, float* v, void* stream);
+/* az_c4_move_fused with the network at fp32 grade (the arithmetic of az_c4net_hx_forward; blob =
+ * az_c4net_hx_blob_bytes() bytes, pack_c4_blob_hx): replaces the same reference lines at the reference's own
+ * network precision (alphazero/mcts.py:94-107 evaluates in fp32).  Every leaf is evaluated alone by one wave,
+ * trunk and heads; same limits, same staging buffers, same use of the evaluation cache.  Results are bit-identical
+ * to the stepwise loop with az_c4net_hx_forward.                                                            */
+int  az_c4_move_fused_hx(az_engine* e, const uint8_t* blob, int32_t num_blocks, uint64_t* leaf_bb,
+                         int32_t* leaf_info, float* p, float* v, void* stream);
 /* largest engine (games) az_c4_move_fused accepts on the engine's device: 64 games per workgroup, one
  * workgroup per compute unit (or per az_c4_move_fused_limit_workgroups)                                 */
 int  az_c4_move_fused_max_games(const az_engine* e);

@@ -36,21 +36,28 @@ def _single_leaf_evaluator(net, memo):
 # regime = how a workgroup with that many games evaluates its leaves (csrc/az_engine.hip, FUSED_FEW_GAMES /
 # FUSED_OWN_HEADS): 'own' = one board per task, heads by the same wave; 'single' = one board per task, heads in
 # shared batches; 'pairs' = two boards per task, heads in shared batches (what 8 192 games on 256 compute units run)
-@pytest.mark.parametrize('G,S,moves,depth,wgs,regime', [
-    (64, 48, 9, 4, 0, 'own'), (64, 200, 4, 2, 0, 'own'), (100, 33, 5, 3, 0, 'own'),
-    (96, 48, 5, 3, 8, 'single'),         # 12 games per workgroup
-    (256, 48, 5, 4, 8, 'pairs'),         # 32 games per workgroup
-    (256, 200, 2, 2, 4, 'pairs'),        # 64 games per workgroup, the most a workgroup takes
-    (250, 33, 3, 2, 5, 'pairs'),         # 50 per workgroup, the last one not full
-    (512, 200, 3, 3, 16, 'pairs'),       # 32 per workgroup on 16 workgroups, 200 simulations
+# prec = 'bf16' (az_c4_move_fused) or 'hx' (az_c4_move_fused_hx: the network at fp32 grade, fp16-pair operands; every
+# leaf a one-board task whose worker runs its heads, whatever the number of games per workgroup)
+@pytest.mark.parametrize('G,S,moves,depth,wgs,regime,prec', [
+    (64, 48, 9, 4, 0, 'own', 'bf16'), (64, 200, 4, 2, 0, 'own', 'bf16'), (100, 33, 5, 3, 0, 'own', 'bf16'),
+    (96, 48, 5, 3, 8, 'single', 'bf16'),         # 12 games per workgroup
+    (256, 48, 5, 4, 8, 'pairs', 'bf16'),         # 32 games per workgroup
+    (256, 200, 2, 2, 4, 'pairs', 'bf16'),        # 64 games per workgroup, the most a workgroup takes
+    (250, 33, 3, 2, 5, 'pairs', 'bf16'),         # 50 per workgroup, the last one not full
+    (512, 200, 3, 3, 16, 'pairs', 'bf16'),       # 32 per workgroup on 16 workgroups, 200 simulations
+    (64, 48, 9, 4, 0, 'own', 'hx'), (100, 200, 3, 2, 0, 'own', 'hx'),
+    (256, 48, 5, 4, 8, 'own', 'hx'),             # 32 games per workgroup
+    (256, 200, 2, 2, 4, 'own', 'hx'),            # 64 games per workgroup
+    (250, 33, 3, 2, 5, 'own', 'hx'),
 ])
-def test_fused_move_kernel_matches_the_oracle(G, S, moves, depth, wgs, regime):
+def test_fused_move_kernel_matches_the_oracle(G, S, moves, depth, wgs, regime, prec):
     from alphazero_amd import engine as E
     from alphazero_amd.models import AlphaZeroC4
-    from alphazero_amd.net import FusedC4Net
+    from alphazero_amd.net import FusedC4Net, FusedC4NetHX
     A = 7
     torch.manual_seed(17)
-    net = FusedC4Net.from_module(AlphaZeroC4(6, 32).eval().cuda(), 'cuda')
+    model = AlphaZeroC4(6, 32).eval().cuda()
+    net = FusedC4NetHX(model, 'cuda') if prec == 'hx' else FusedC4Net.from_module(model, 'cuda')
     lut_np = load_lut()
     rng = np.random.RandomState(1000 + G + S)
     etas = rng.dirichlet([0.3] * A, size=(G, moves))          # slot-indexed; the first n_edges are used
