@@ -350,7 +350,11 @@ class FusedC4NetHX:
         self.lib = _lib.load()
         self.device = _device(device if device is not None else next(model.parameters()).device)
         self.num_blocks = model.num_blocks
-        self.blob = pack_c4_blob_hx(model).to(self.device)
+        blob = pack_c4_blob_hx(model)
+        # as FusedC4Net: header + kernel-ready blob in one buffer, so that distributed.broadcast_packed can ship it
+        self.wire = torch.zeros(WIRE_HEADER + blob.numel(), dtype=torch.uint8, device=self.device)
+        self.blob = self.wire[WIRE_HEADER:]
+        self.blob.copy_(blob)
         assert self.blob.data_ptr() % 16 == 0
         self._p = self._v = None
 

@@ -38,7 +38,12 @@ def record_to_game(game_cls, rec):
 
 class SelfPlayWorker:
     def __init__(self, config, model_server, dataset, device, num_games=1024, seed=0,
-                 rank=0, world_size=1, evaluator=None, eval_cache_log2=0):
+                 rank=0, world_size=1, evaluator=None, eval_cache_log2=0, net_precision='bf16'):
+        # net_precision (Connect Four networks with up to 32 trunk channels): 'bf16' = the bf16 MFMA network, the
+        # fast path; 'fp32' = the network at the reference's own precision (alphazero/mcts.py:94-107 evaluates in
+        # fp32) on fp16-pair operands, outputs within 1e-5 of the torch module, about a third of the bf16 rate
+        if net_precision not in ('bf16', 'fp32'):
+            raise ValueError("net_precision is 'bf16' or 'fp32'")
         if evaluator is not None and eval_cache_log2:
             # az_sim_step answers cached leaves by writing rows of the (p, v) buffers it is given; a
             # caller's evaluator may return fresh tensors or leave other rows undefined, which would feed
@@ -69,9 +74,10 @@ class SelfPlayWorker:
             # kernels, tic-tac-toe (4, 8 or 16 channels) in its own fp32 kernel; anything else is
             # evaluated by calling the torch module on the rendered leaves
             from .models import AlphaZero, AlphaZeroC4
-            from .net import CMAX, C4Net128, FusedC4Net, TTTNetF32
+            from .net import CMAX, C4Net128, FusedC4Net, FusedC4NetHX, TTTNetF32
             if isinstance(self._model, AlphaZeroC4) and self._model.block_channels <= CMAX:
-                self._fused = FusedC4Net.from_module(self._model, self._device)
+                self._fused = (FusedC4NetHX(self._model, self._device) if net_precision == 'fp32'
+                               else FusedC4Net.from_module(self._model, self._device))
             elif isinstance(self._model, AlphaZeroC4) and self._model.block_channels == 128:
                 self._fused = C4Net128(self._model, self._device, max_leaves=self.num_games)
             elif (type(self._model) is AlphaZero and self._game_cls.AZ_GAME_ID == _engine._lib.GAME_TTT
@@ -86,8 +92,8 @@ class SelfPlayWorker:
             self.engine.enable_eval_cache(eval_cache_log2)
         # Connect Four with the <= 32-channel network: a whole move's simulations run in one launch
         # (az_c4_move_fused)
-        from .net import FusedC4Net as _F
-        self._fused_move = (isinstance(self._fused, _F) and evaluator is None
+        from .net import FusedC4Net as _F, FusedC4NetHX as _FH
+        self._fused_move = (isinstance(self._fused, (_F, _FH)) and evaluator is None
                             and self.num_games <= self.engine.fused_max_games())
         if self._fused is not None and not self._fused_move and self.num_games > 32768:
             raise ValueError('the HIP network kernels take at most 32768 leaves per call: num_games <= 32768')

@@ -85,6 +85,33 @@ def test_c4_net_fused_and_torch_paths():
         assert w.engine.stats()['errors'] == 0
 
 
+def test_c4_net_at_fp32_grade_one_launch_and_stepwise_play_the_same_games():
+    """net_precision='fp32': the worker evaluates with the fp16-pair network (outputs within 1e-5 of the torch
+    module, alphazero/mcts.py:94-107 evaluates in fp32).  With the one-launch move kernel and with the stepwise
+    loop it must produce the very same games (same seed, device RNG), visit counts included."""
+    from alphazero_amd.models import AlphaZeroC4
+    from alphazero_amd.net import FusedC4NetHX
+    from alphazero_amd.selfplay import SelfPlayWorker
+    model = {'module': 'alphazero.games.connectfour', 'name': 'AlphaZeroC4',
+             'kwargs': {'num_blocks': 3, 'channels_per_block': 32}}
+    cfg = _config({'module': 'alphazero.games.connectfour', 'name': 'ConnectFour'}, model, S=40)
+    torch.manual_seed(0)
+    state = AlphaZeroC4(3, 32).state_dict()
+    played = []
+    for one_launch in (True, False):
+        ds, srv = _Dataset(), _Server(4, state)
+        w = SelfPlayWorker(cfg, srv, ds, 'cuda', num_games=40, seed=3, net_precision='fp32')
+        assert isinstance(w._fused, FusedC4NetHX) and w._fused_move
+        w._fused_move = one_launch
+        for _ in range(30):
+            w.play_game()
+        _check_games(ds, orc.C4, 40, True)
+        assert w.engine.stats()['errors'] == 0
+        played.append(sorted((tuple(g.history), tuple(int(x) for n in g.search_statistics for x in n)) for g, _ in ds.games))
+        w.engine.close()
+    assert len(played[0]) > 20 and played[0] == played[1]
+
+
 def test_c4_net_128_channels_uses_the_tower_kernel():
     from alphazero_amd.models import AlphaZeroC4
     from alphazero_amd.net import C4Net128
