@@ -271,6 +271,89 @@ def config4_leaf_eval(dev, iters=10, n=16384):
             'flops_per_leaf': trunk_flops_per_leaf(10, 128), 'dtype': 'bf16 MFMA, f32 accumulate'}
 
 
+def selfplay_10x128(dev, games=8192, sims=800, steps=2, halves=1, seed=1, blocks=10, mix_moves=40, record_sink=None):
+    """Self-play with the 10x128 network of BASELINE config 4 (alphazero/models.py:70-87 at that size inside
+    alphazero/selfplay.py:24-38): the stepwise loop, one search launch and one network evaluation (leaf list, stem,
+    tower, heads) per simulation.  halves = 2 splits the games over two engines on two HIP streams, so that one
+    half's search step and small network kernels can run under the other half's tower; the halves own the game
+    uids of the one-engine run (same device RNG streams), so the finished games are the same ones."""
+    import torch
+    from alphazero_amd import engine as E
+    from alphazero_amd.models import AlphaZeroC4
+    from alphazero_amd.net import C4Net128
+    torch.manual_seed(0)
+    model = AlphaZeroC4(blocks, 128).to(dev).eval()
+    per = games // halves
+    engs = [E.SelfPlayEngine(E._lib.GAME_C4, per, sims, exploration_depth=4, reuse_search_tree=True, alpha=0.3,
+                             epsilon=0.25, seed=seed, device=dev.index, first_game_uid=h * per, uid_stride=games)
+            for h in range(halves)]
+    nets = [C4Net128(model, dev, max_leaves=per) for _ in range(halves)]
+    torch.cuda.synchronize()                       # buffers made on the current stream, used on the halves' streams
+    streams = [torch.cuda.Stream(device=dev) for _ in range(halves)] if halves > 1 else [torch.cuda.current_stream(dev)]
+    tower_ev = []
+
+    def step(measure=False):
+        st = [None] * halves
+        for h, (eng, net) in enumerate(zip(engs, nets)):
+            with torch.cuda.stream(streams[h]):
+                bb, info = eng.begin_move()
+                p, _ = net(bb, info)
+                eng.apply_root(p)
+                st[h] = eng.select()
+        for s_ in range(sims):
+            for h, (eng, net) in enumerate(zip(engs, nets)):
+                with torch.cuda.stream(streams[h]):
+                    sample = measure and h == 0 and s_ % 32 == 7
+                    if sample:
+                        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        a.record()
+                    p, v = net(*st[h])
+                    if sample:
+                        b.record()
+                        tower_ev.append((a, b))
+                    if s_ < sims - 1:
+                        st[h] = eng.sim_step(p, v)
+                    else:
+                        eng.expand_backup(p, v)
+        for h, eng in enumerate(engs):
+            with torch.cuda.stream(streams[h]):
+                eng.choose_and_advance()
+                raw = eng.drain_finished_bytes()
+                if record_sink is not None:
+                    record_sink.append(raw.copy())
+    for i in range(mix_moves):                     # spread the games' ages first (uniform prior: cheap)
+        for h, eng in enumerate(engs):
+            with torch.cuda.stream(streams[h]):
+                eng.begin_move_uniform()
+                eng.run_sims_uniform(sims)
+                eng.choose_and_advance()
+                if i % 2 == 1:
+                    raw = eng.drain_finished_bytes()
+                    if record_sink is not None:
+                        record_sink.append(raw.copy())
+    step()
+    st0 = [eng.stats() for eng in engs]
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        step(True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t1) / steps
+    st1 = [eng.stats() for eng in engs]
+    d_sims = sum(b['sims'] - a['sims'] for a, b in zip(st0, st1))
+    leaves = sum(b['leaf_evals'] - a['leaf_evals'] for a, b in zip(st0, st1))
+    assert d_sims == games * sims * steps and all(b['errors'] == 0 for b in st1)
+    net_ms = sum(a.elapsed_time(b) for a, b in tower_ev) / max(len(tower_ev), 1)
+    per_launch = leaves / (steps * sims * halves)
+    tf = per_launch * trunk_flops_per_leaf(blocks, 128) / (net_ms * 1e-3) / 1e12 if halves == 1 else None
+    for eng in engs:
+        eng.close()
+    return {'value': games / dt, 'unit': 'positions/s', 'sims_per_s': games * sims / dt, 'ms_per_step': 1e3 * dt,
+            'steps': steps, 'engines_on_streams': halves, 'leaves_per_network_call': per_launch,
+            'network_call_ms': net_ms if halves == 1 else None,
+            'network_tflops_in_loop': tf, 'network_frac_of_bf16_peak': tf / BF16_PEAK_TFLOPS if tf else None}
+
+
 def config2_selfplay(dev, fused, games=1024, sims=200, steps=12):
     """BASELINE config 2: 1 024 concurrent Connect Four games, 200 simulations per move, on one GPU; the same path
     as the headline line (one az_c4_move_fused launch per move, four games per compute unit here)."""
@@ -789,6 +872,16 @@ def main():
             extra('config2_selfplay', lambda: config2_selfplay(dev, fused))
             extra('config4_leaf_eval', lambda: config4_leaf_eval(dev))
             extra('config5_train_loop', extra_config5)
+
+            def extra_10x128():
+                # (f) self-play with the 10x128 network (BASELINE config 4's network inside the config-3 loop), one
+                # engine and two engines on two streams
+                one = selfplay_10x128(dev, G, S, steps=2, halves=1)
+                two = selfplay_10x128(dev, G, S, steps=2, halves=2)
+                one['workload'] = f'connect4 self-play, {S} sims/move, {G} games/GPU, model c4_10x128, stepwise loop'
+                one['two_halves_on_two_streams'] = {k: two[k] for k in ('value', 'ms_per_step', 'leaves_per_network_call')}
+                return one
+            extra('selfplay_10x128', extra_10x128)
         if not args.no_cpu_baseline and not multi:      # the host-CPU baseline is timed at N = 1 only
             logical, physical = physical_cores()
             workers = cpu_share()

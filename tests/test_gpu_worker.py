@@ -349,3 +349,22 @@ def test_data_parallel_play_and_train_two_ranks(tmp_path):
     port = 33500 + (os.getpid() % 2000)
     mp.spawn(_dp_train_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(tmp_path / 'dp0') and os.path.exists(tmp_path / 'dp1')
+
+
+def test_self_play_split_over_two_streams_finishes_the_same_games():
+    """bench.py's 128-channel self-play loop with the games split over two engines on two HIP streams (each half
+    owns the game uids it would have in the one-engine run): the finished-game records are the same bytes."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    dev = torch.device('cuda', 0)
+    got = []
+    for halves in (1, 2):
+        sink = []
+        out = bench.selfplay_10x128(dev, games=64, sims=16, steps=6, halves=halves, blocks=2, mix_moves=6, record_sink=sink)
+        assert out['engines_on_streams'] == halves and out['value'] > 0
+        recs = np.concatenate([r for r in sink if r.shape[0]], axis=0)
+        got.append(sorted(bytes(r) for r in recs))
+    assert len(got[0]) > 10 and got[0] == got[1]
+
