@@ -243,6 +243,49 @@ int  az_masked_softmax(int32_t game, const float* logits, const int32_t* leaf_in
 int  az_ucb_score(az_engine* e, const uint32_t* N, const float* W, const float* P,
                   const int32_t* num_edges, int32_t n, double* score, int32_t* argmax, void* stream);
 
+/* ---- training step of the Connect Four network, hand-written forward and backward ---------------------------
+ * Replaces, for AlphaZeroC4 with 32 trunk channels in training mode, the forward, loss and backward of
+ * alphazero/training.py:57-71 (model(x, p_valid), AlphaZeroLoss, total.backward(): alphazero/models.py:6-87,
+ * games/connectfour.py:47-72, loss.py:29-63) -- fp32, batch-norm on the statistics of the batch, running statistics
+ * updated as torch does (momentum bn_momentum, unbiased variance, once per application of the shared block).  All
+ * pointers are DEVICE pointers to tensors in torch's own layouts (conv weights [co][ci][ky][kx], linear weights
+ * [out][in]); every *_grad tensor is overwritten with d(policy loss + value loss) / d(parameter).                */
+typedef struct az_bn {
+    const float* weight; const float* bias;              /* [channels] */
+    float* running_mean; float* running_var;             /* [channels], updated */
+    int64_t* num_batches_tracked;                        /* [1], incremented once per application */
+    float* weight_grad; float* bias_grad;
+} az_bn;
+typedef struct az_c4_train_net {
+    int32_t num_blocks, reserved;
+    float bn_momentum, bn_eps;                           /* torch defaults: 0.1, 1e-5 */
+    const float* stem_w; float* stem_w_grad;             /* [32][2][3][3] */
+    az_bn stem_bn;
+    const float* c1_w; float* c1_w_grad; az_bn bn1;      /* the shared residual block: [32][32][3][3] each */
+    const float* c2_w; float* c2_w_grad; az_bn bn2;
+    const float* pol_conv_w; float* pol_conv_w_grad;     /* [2][32][1][1] */
+    const float* pol_conv_b; float* pol_conv_b_grad;     /* [2] */
+    az_bn pol_bn;
+    const float* pol_fc_w; float* pol_fc_w_grad;         /* [42][84] */
+    const float* pol_fc_b; float* pol_fc_b_grad;         /* [42] */
+    const float* val_conv_w; float* val_conv_w_grad;     /* [1][32][1][1] */
+    az_bn val_bn;
+    const float* val_fc1_w; float* val_fc1_w_grad;       /* [256][42] */
+    const float* val_fc1_b; float* val_fc1_b_grad;       /* [256] */
+    const float* val_fc2_w; float* val_fc2_w_grad;       /* [1][256] */
+    const float* val_fc2_b; float* val_fc2_b_grad;       /* [1] */
+} az_c4_train_net;
+/* bytes of DEVICE workspace az_c4_train_fwd_bwd needs for this batch size and depth (contents need not be kept
+ * between calls)                                                                                              */
+long az_c4_train_workspace_bytes(int32_t batch, int32_t num_blocks);
+/* x float [batch][2][6][7] (ConnectFour.render planes), valid uint8 [batch][7], target_p float [batch][7], z float
+ * [batch]; out3 DEVICE float[3] = {policy loss, value loss, max |sum(target) - 1|} as az_loss_fwd_bwd;
+ * logits7_out [batch][7] / vhat_out [batch] receive the network's outputs when not NULL.  4 * num_blocks + 11
+ * launches on `stream`, no allocation, no host synchronisation (it can be recorded in a HIP graph).  batch >= 2. */
+int  az_c4_train_fwd_bwd(const az_c4_train_net* net, const float* x, const uint8_t* valid, const float* target_p,
+                         const float* z, int32_t batch, void* workspace, float* out3, float* logits7_out,
+                         float* vhat_out, void* stream);
+
 /* ---- fused Connect Four network forward (K8/K12) ---------------------------
  * Whole AlphaZeroC4 forward (alphazero/models.py:70-87, connectfour.py:54-72) for n
  * leaves given as bitboards, BN folded, trunk channels <= 32, bf16 MFMA trunk with
