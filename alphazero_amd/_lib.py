@@ -95,6 +95,7 @@ SIGNATURES = {
     'az_sgd_momentum': (C.c_int, [_P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int32, _P]),
     'az_sgd_momentum_lr_dev': (C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_float, C.c_float, _P]),
     'az_sgd_momentum_guarded': (C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_float, C.c_float, _P, C.c_float, _P, _P]),
+    'az_sample_window': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, _P, C.c_int32, C.c_uint64, _P, C.c_int32, _P, _P, _P, _P, _P]),
     'az_c4_train_workspace_bytes': (C.c_long, [C.c_int32, C.c_int32]),
     'az_c4_train_fwd_bwd': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P, _P]),
     'az_tttnet_f32_blob_floats': (C.c_int, [C.c_int32]),

@@ -5,7 +5,9 @@
 //   * az_sgd_momentum : torch.optim.SGD's update (momentum, weight decay, no dampening, no Nesterov --
 //                       training.py:27-29) over ONE flat parameter / gradient / momentum buffer, in one launch
 //                       instead of three per tensor.
-// The convolutions' forward and backward in between stay with the vendor library that PyTorch calls.
+//   * az_sample_window: a batch drawn from the device-resident replay window (ReplayBufferSampler,
+//                       alphazero/replay_buffer.py:175-195) and gathered, in one launch.
+// The network's forward and backward: az_train_c4.hip for the 32-channel Connect Four network, PyTorch otherwise.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -107,7 +109,70 @@ k_sgd_guarded(float* __restrict__ p, const float* __restrict__ g, float* __restr
     p[i] = fmaf(-lr, b, p[i]);
 }
 
+// ---- a training batch drawn from the device-resident replay window, in one launch ------------------------------
+__device__ __forceinline__ uint32_t mix32(uint64_t seed, uint64_t draw, uint32_t i, uint32_t attempt) {
+    // splitmix64 over a key that is unique per (seed, draw, sample, attempt)
+    uint64_t zz = seed + 0x9E3779B97F4A7C15ull * (draw * 0x100000001B3ull + ((uint64_t)i << 20) + attempt + 1);
+    zz = (zz ^ (zz >> 30)) * 0xBF58476D1CE4E5B9ull;
+    zz = (zz ^ (zz >> 27)) * 0x94D049BB133111EBull;
+    zz ^= zz >> 31;
+    return (uint32_t)(zz >> 32);
+}
+
+#define SAMPLE_MAX_WINDOW (1 << 18)          // states: one bit each in LDS
+#define SAMPLE_MAX_BATCH 2048
+__global__ void __launch_bounds__(256)
+k_sample_window(const float* __restrict__ wx, const float* __restrict__ wp, const float* __restrict__ wz,
+                const uint8_t* __restrict__ wvalid, int x_floats, int A, const long long* __restrict__ count_dev, int capacity,
+                unsigned long long seed, long long* __restrict__ draw_dev, int batch, float* __restrict__ x, float* __restrict__ p,
+                float* __restrict__ z, uint8_t* __restrict__ valid) {
+    __shared__ uint32_t taken[SAMPLE_MAX_WINDOW / 32];
+    __shared__ int pick[SAMPLE_MAX_BATCH];
+    const int tid = threadIdx.x;
+    const long long count = count_dev[0];
+    const int n = count < capacity ? (int)count : capacity;
+    const unsigned long long draw = (unsigned long long)draw_dev[0];
+    for (int i = tid; i < (n + 31) / 32; i += 256) taken[i] = 0u;
+    __syncthreads();
+    if (tid == 0) {
+        // uniform without replacement while the window holds at least a batch (each draw is rejected while it repeats
+        // an earlier one), with replacement otherwise (alphazero/replay_buffer.py:188-195)
+        const bool distinct = batch <= n;
+        for (int i = 0; i < batch; ++i) {
+            uint32_t r, attempt = 0;
+            for (;;) {
+                r = (uint32_t)(((uint64_t)mix32(seed, draw, (uint32_t)i, attempt++) * (uint64_t)n) >> 32);
+                if (!distinct || !((taken[r >> 5] >> (r & 31)) & 1u)) break;
+            }
+            taken[r >> 5] |= 1u << (r & 31);
+            pick[i] = (int)(((long long)r + (count - n)) % capacity);       // the i-th oldest state sits at (count - n + i) % capacity
+        }
+        draw_dev[0] = (long long)(draw + 1);
+    }
+    __syncthreads();
+    for (int i = tid; i < batch * x_floats; i += 256) x[i] = wx[(size_t)pick[i / x_floats] * x_floats + i % x_floats];
+    for (int i = tid; i < batch * A; i += 256) {
+        p[i] = wp[(size_t)pick[i / A] * A + i % A];
+        valid[i] = wvalid[(size_t)pick[i / A] * A + i % A];
+    }
+    for (int i = tid; i < batch; i += 256) z[i] = wz[pick[i]];
+}
+
 extern "C" {
+
+int az_sample_window(const float* wx, const float* wp, const float* wz, const uint8_t* wvalid, int32_t x_floats,
+                     int32_t num_actions, const int64_t* count_dev, int32_t capacity, uint64_t seed, int64_t* draw_dev,
+                     int32_t batch, float* x, float* p, float* z, uint8_t* valid, void* stream) {
+    if (!wx || !wp || !wz || !wvalid || !count_dev || !draw_dev || !x || !p || !z || !valid)
+        return az_fail("az_sample_window: null pointer");
+    if (batch <= 0 || batch > SAMPLE_MAX_BATCH || capacity <= 0 || capacity > SAMPLE_MAX_WINDOW || x_floats <= 0 || num_actions <= 0)
+        return az_fail("az_sample_window: batch <= 2048 states from a window of at most 262144");
+    hipLaunchKernelGGL(k_sample_window, dim3(1), dim3(256), 0, (hipStream_t)stream, wx, wp, wz, wvalid, (int)x_floats,
+                       (int)num_actions, reinterpret_cast<const long long*>(count_dev), (int)capacity,
+                       (unsigned long long)seed, reinterpret_cast<long long*>(draw_dev), (int)batch, x, p, z, valid);
+    AZ_LAUNCH_CHECK("k_sample_window");
+    return 0;
+}
 
 int az_loss_fwd_bwd(int32_t num_actions, const float* logits, const float* v_hat, const float* target, const float* z,
                     const uint8_t* valid, int32_t batch, float* out3, float* dlogits, float* dv, void* stream) {

@@ -5,10 +5,12 @@
 //
 // Batch-norm runs in training mode (statistics of the batch), so every conv is followed by a reduction over the
 // whole batch before the next layer can start, and every layer's backward by another one.  The step is therefore
-// a chain of 4 * blocks + 11 launches (35 for the shipped 6 x 32 network), each of which ends with the reduction
-// the next one needs: a workgroup owns one board (42 cells x 32 channels; the conv's halo is the zero padding, so
-// workgroups share nothing), writes its partial sums, and the last workgroup to finish adds the partial sums up
-// in a fixed order (deterministic) and leaves the statistics for the next launch.
+// a chain of 4 * blocks + 11 launches (35 for the shipped 6 x 32 network) with the launch boundaries as the only
+// synchronisation: a workgroup owns one board (42 cells x 32 channels; the conv's halo is the zero padding, so
+// workgroups share nothing) and ends by writing its board's partial sums; every workgroup of the NEXT launch begins
+// by adding all boards' partial sums up for itself (32 KB from L2, fixed order, double precision: deterministic, no
+// atomics, no fences).  (A first version let the last workgroup of a launch do that sum behind a device-scope
+// counter: 18 of each launch's 30 us went into it.)
 //   * activations: channel-last fp32 [board][cell][32]; kept per layer: the raw conv outputs Z (batch-norm input)
 //     and the block inputs X; everything else (ReLU(BN(Z)), x-hat, ReLU masks) is recomputed from those while a
 //     tile is staged into LDS;
@@ -30,72 +32,75 @@
 #define TC 32                  // trunk channels
 #define CELLS 42
 #define PADCELLS 72            // the board with its zero halo: rows -1..6, columns -1..7
-#define TT 256                 // threads per workgroup
-#define NPOS 6                 // cells per thread in the conv loops (8 groups x 6 >= 42)
+#define TT 256                 // threads per workgroup of the small kernels: thread = (channel, one of 8 cell groups)
+#define NPOS 6                 // cells per thread there (8 groups x 6 >= 42)
+#define TTC 512                // threads per workgroup of the 3x3 conv kernels: two waves per SIMD, 16 cell groups
+#define NPC 3                  // cells per thread there (16 groups x 3 >= 42): cell = group + 16 k
+#define EPT 3                  // elements of a board tensor [42][32] per thread of a conv kernel: element tid + 512 j is
+                               // (cell = group + 16 j, channel = tid & 31) -- the same cells the thread computes
 
 __device__ __forceinline__ int pad_index(int cell) { return (cell / 7 + 1) * 9 + cell % 7 + 1; }
 __device__ __forceinline__ int tap_offset(int tap) { return (tap / 3 - 1) * 9 + tap % 3 - 1; }
 
-// a float written by another workgroup of this launch (partial sums): read past the vector cache
-__device__ __forceinline__ float load_partial(const float* p) {
-    return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const unsigned int*>(p), __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_AGENT));
-}
-
-// The workgroups of a launch have written part[board][64]; the last one to arrive adds them up (columns < ncol and
-// 32 .. 32 + ncol are used) and returns true with the totals in tot[0..63] (LDS, double).  Fixed order of
-// addition whatever the arrival order.
-__device__ bool last_block_totals(const float* part, int boards, int* counter, double* tot /* LDS [64] */,
-                                  double* scratch /* LDS [4][64] */) {
-    __shared__ int s_last;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = (atomicAdd(counter, 1) == (int)gridDim.x - 1);
-    __syncthreads();
-    if (!s_last) return false;
-    __threadfence();
-    const int col = threadIdx.x & 63, q = threadIdx.x >> 6;
+// The workgroups of the PREVIOUS launch have each written a row part[board][64] (two quantities x 32 channels, summed
+// over the board's cells).  Every workgroup of this launch adds the rows up for itself, in board order, in double:
+// 32 KB of L2 reads, no atomics, no fences, the same bits in every workgroup and every run.  tot = LDS [64].
+__device__ __forceinline__ void reduce_partials(const float* __restrict__ part, int boards, double* tot,
+                                                double* scratch /* LDS [8][64] */) {
+    const int col = threadIdx.x & 63, q = threadIdx.x >> 6, nq = blockDim.x >> 6;
     double s = 0.0;
-    for (int b = q; b < boards; b += 4) s += (double)load_partial(part + (size_t)b * 64 + col);
+    for (int b0 = q; b0 < boards; b0 += 32 * nq) {         // up to 32 loads in flight (one trip to memory for 128
+        float v[32];                                       // boards), added in board order
+#pragma unroll
+        for (int j = 0; j < 32; ++j) v[j] = b0 + nq * j < boards ? part[(size_t)(b0 + nq * j) * 64 + col] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) s += (double)v[j];
+    }
     scratch[q * 64 + col] = s;
     __syncthreads();
-    if (threadIdx.x < 64) tot[threadIdx.x] = scratch[col] + scratch[64 + col] + scratch[128 + col] + scratch[192 + col];
-    if (threadIdx.x == 0) *counter = 0;                    // ready for the next launch
+    if (threadIdx.x < 64) {
+        double t = 0.0;
+        for (int k = 0; k < nq; ++k) t += scratch[k * 64 + col];
+        tot[threadIdx.x] = t;
+    }
     __syncthreads();
-    return true;
 }
 
 // per board: the 32 (or fewer) column sums of two quantities over the board's cells, from per-thread values
 // (thread = (channel = tid & 31, group = tid >> 5)), into part[board][0..31] and part[board][32..63]
-__device__ __forceinline__ void board_partials(float a, float b, float* red /* LDS [2][8][32] */, float* part_row) {
-    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+__device__ __forceinline__ void board_partials(float a, float b, float* red /* LDS [2][groups][32] */, float* part_row) {
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5, ng = blockDim.x >> 5;
     red[g * 32 + c] = a;
-    red[256 + g * 32 + c] = b;
+    red[ng * 32 + g * 32 + c] = b;
     __syncthreads();
     if (threadIdx.x < 64) {
-        const float* r = red + (threadIdx.x >> 5) * 256 + (threadIdx.x & 31);
+        const float* r = red + (threadIdx.x >> 5) * ng * 32 + (threadIdx.x & 31);
         float s = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s += r[k * 32];
+        for (int k = 0; k < ng; ++k) s += r[k * 32];
         part_row[threadIdx.x] = s;
     }
 }
 
-// statistics of a batch-norm input from the totals (sum, sum of squares): stat[0..31] mean, [32..63] 1/sqrt(var +
-// eps), [64..95] biased variance
-__device__ __forceinline__ void write_stats(const double* tot, int nch, long n, float eps, float* stat) {
+// statistics of a batch-norm input from the totals (sum, sum of squares): st[0..31] mean, [32..63] 1/sqrt(var + eps),
+// [64..95] biased variance -- into LDS for this workgroup, and by workgroup 0 into `keep` for the launches to come
+__device__ __forceinline__ void stats_from_totals(const double* tot, int nch, long n, float eps, float* st /* LDS [96] */,
+                                                  float* keep) {
     if ((int)threadIdx.x < nch) {
         const int c = threadIdx.x;
         const double mean = tot[c] / (double)n;
         double var = tot[32 + c] / (double)n - mean * mean;
         if (var < 0.0) var = 0.0;
-        stat[c] = (float)mean;
-        stat[32 + c] = (float)(1.0 / sqrt(var + (double)eps));
-        stat[64 + c] = (float)var;
+        st[c] = (float)mean;
+        st[32 + c] = (float)(1.0 / sqrt(var + (double)eps));
+        st[64 + c] = (float)var;
+        if (blockIdx.x == 0) { keep[c] = st[c]; keep[32 + c] = st[32 + c]; keep[64 + c] = st[64 + c]; }
     }
+    __syncthreads();
 }
 
-struct BnRef { const float* stat; const float* gamma; const float* beta; };
+// a batch-norm whose statistics are being made by this launch (from the previous launch's partial sums) and kept
+// in stat_keep [96] for later launches
+struct BnRef { float* stat_keep; const float* gamma; const float* beta; };
 
 // ---------------------------------------------------------------------------------------------------------
 // forward
@@ -105,7 +110,7 @@ struct BnRef { const float* stat; const float* gamma; const float* beta; };
 __global__ void __launch_bounds__(TT)
 k_train_prep(const float* __restrict__ c1, const float* __restrict__ c2, const float* __restrict__ stem, float* __restrict__ wf1,
              float* __restrict__ wb1, float* __restrict__ wf2, float* __restrict__ wb2, float* __restrict__ ws,
-             float* __restrict__ bn_acc /* [3][64] */, int* __restrict__ counter) {
+             float* __restrict__ bn_acc /* [3][64] */) {
     const int i = blockIdx.x * TT + threadIdx.x;
     if (i < 9 * TC * TC) {
         const int tap = i / (TC * TC), ci = (i / TC) % TC, co = i % TC;
@@ -118,17 +123,14 @@ k_train_prep(const float* __restrict__ c1, const float* __restrict__ c2, const f
         ws[i] = stem[(co * 2 + plane) * 9 + tap];
     }
     if (i < 3 * 64) bn_acc[i] = 0.0f;
-    if (i == 0) *counter = 0;
 }
 
-// stem: conv 2 -> 32 from the rendered planes x [board][2][6][7] -> Z0, statistics of Z0
+// stem: conv 2 -> 32 from the rendered planes x [board][2][6][7] -> Z0 and the board's sums of Z0, Z0^2
 __global__ void __launch_bounds__(TT)
-k_train_stem_fwd(const float* __restrict__ x, const float* __restrict__ ws, float* __restrict__ zout, float* __restrict__ part,
-                 int* counter, float* __restrict__ stat_out, int boards, float eps) {
+k_train_stem_fwd(const float* __restrict__ x, const float* __restrict__ ws, float* __restrict__ zout, float* __restrict__ part_out) {
     __shared__ float xt[PADCELLS * 2];
     __shared__ float wl[18 * TC];
     __shared__ float red[512];
-    __shared__ double tot[64], scratch[256];
     const int b = blockIdx.x, tid = threadIdx.x, co = tid & 31, g = tid >> 5;
     for (int i = tid; i < PADCELLS * 2; i += TT) xt[i] = 0.0f;
     for (int i = tid; i < 18 * TC; i += TT) wl[i] = ws[i];
@@ -151,21 +153,21 @@ k_train_stem_fwd(const float* __restrict__ x, const float* __restrict__ ws, floa
         zout[((size_t)b * CELLS + cell) * TC + co] = acc;
         s += acc; q = fmaf(acc, acc, q);
     }
-    board_partials(s, q, red, part + (size_t)b * 64);
-    if (last_block_totals(part, boards, counter, tot, scratch)) write_stats(tot, TC, (long)boards * CELLS, eps, stat_out);
+    board_partials(s, q, red, part_out + (size_t)b * 64);
 }
 
-// scale / shift of a batch-norm in training mode from its statistics: y = z * sc + sh
-__device__ __forceinline__ void bn_scale_shift(const BnRef& bn, float* sc, float* sh) {
+// scale / shift of a batch-norm in training mode from its statistics (LDS): y = z * sc + sh
+__device__ __forceinline__ void bn_scale_shift(const float* st, const float* gamma, const float* beta, float* sc, float* sh) {
     if (threadIdx.x < TC) {
         const int c = threadIdx.x;
-        const float k = bn.gamma[c] * bn.stat[32 + c];
+        const float k = gamma[c] * st[32 + c];
         sc[c] = k;
-        sh[c] = bn.beta[c] - bn.stat[c] * k;
+        sh[c] = beta[c] - st[c] * k;
     }
 }
 
-// the board's input activation into the padded LDS tile: A = ReLU(BN(Zin) (+ Xprev)); stored to xout when given
+// the board's input activation into the padded LDS tile, for the head kernel (256 threads):
+// A = ReLU(BN(Zin) (+ Xprev)); stored to xout when given
 template <bool RES, bool WRITE_X>
 __device__ __forceinline__ void stage_activation(float* tile, const float* zin, const float* xprev, float* xout,
                                                  const float* sc, const float* sh, int b) {
@@ -184,11 +186,11 @@ __device__ __forceinline__ void stage_activation(float* tile, const float* zin, 
 // acc[k] = sum over taps and input channels of tile[cell_k + SIGN * tap offset][ci] * w[tap][ci][out]: the forward
 // conv (SIGN = +1, w = [tap][ci][co], out = co) and the input gradient (SIGN = -1, w = [tap][co][ci], out = ci)
 template <int SIGN>
-__device__ __forceinline__ void conv_cells(const float* tile, const float* w, int out, int g, float (&acc)[NPOS]) {
-    int pi[NPOS];
+__device__ __forceinline__ void conv_cells(const float* tile, const float* w, int out, int g, float (&acc)[NPC]) {
+    int pi[NPC];
 #pragma unroll
-    for (int k = 0; k < NPOS; ++k) {
-        const int cell = g + 8 * k;
+    for (int k = 0; k < NPC; ++k) {
+        const int cell = g + 16 * k;
         pi[k] = pad_index(cell < CELLS ? cell : 0);
         acc[k] = 0.0f;
     }
@@ -196,11 +198,11 @@ __device__ __forceinline__ void conv_cells(const float* tile, const float* w, in
     for (int tap = 0; tap < 9; ++tap) {
         const int off = SIGN * tap_offset(tap);
         const float* wt = w + tap * TC * TC + out;
-#pragma unroll 2
+#pragma unroll 4
         for (int c4 = 0; c4 < TC / 4; ++c4) {
             const float w0 = wt[(4 * c4) * TC], w1 = wt[(4 * c4 + 1) * TC], w2 = wt[(4 * c4 + 2) * TC], w3 = wt[(4 * c4 + 3) * TC];
 #pragma unroll
-            for (int k = 0; k < NPOS; ++k) {
+            for (int k = 0; k < NPC; ++k) {
                 const float4 a = *reinterpret_cast<const float4*>(tile + (pi[k] + off) * TC + 4 * c4);
                 acc[k] = fmaf(a.x, w0, acc[k]);
                 acc[k] = fmaf(a.y, w1, acc[k]);
@@ -211,56 +213,99 @@ __device__ __forceinline__ void conv_cells(const float* tile, const float* w, in
     }
 }
 
-// one 3x3 conv of the tower: Zout = conv(A), A = ReLU(BN(Zin) (+ Xprev)), statistics of Zout
+// the conv's 36 KB of weights, global -> registers (issued early) -> LDS
+struct WRegs { float4 r[5]; };
+__device__ __forceinline__ WRegs load_conv_weights(const float* __restrict__ w) {
+    WRegs x;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int i = threadIdx.x + j * TTC;
+        x.r[j] = i < 9 * TC * TC / 4 ? reinterpret_cast<const float4*>(w)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return x;
+}
+__device__ __forceinline__ void store_conv_weights(float* wl, const WRegs& x) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int i = threadIdx.x + j * TTC;
+        if (i < 9 * TC * TC / 4) reinterpret_cast<float4*>(wl)[i] = x.r[j];
+    }
+}
+
+// one 3x3 conv of the tower: Zout = conv(A), A = ReLU(BN(Zin) (+ Xprev)); BN's statistics from part_in (the sums of
+// Zin, Zin^2 per board); the board's sums of Zout, Zout^2 -> part_out.  Every global load of the launch is issued
+// before the first wait: what the previous launch wrote comes from beyond this chip's L2 (2 us), once.
 template <bool RES, bool WRITE_X>
-__global__ void __launch_bounds__(TT)
-k_train_conv_fwd(const float* __restrict__ zin, BnRef bn, const float* __restrict__ xprev, float* __restrict__ xout,
-                 const float* __restrict__ wf, float* __restrict__ zout, float* __restrict__ part, int* counter,
-                 float* __restrict__ stat_out, int boards, float eps) {
+__global__ void __launch_bounds__(TTC)
+k_train_conv_fwd(const float* __restrict__ zin, const float* __restrict__ part_in, BnRef bn, const float* __restrict__ xprev,
+                 float* __restrict__ xout, const float* __restrict__ wf, float* __restrict__ zout, float* __restrict__ part_out,
+                 int boards, float eps) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wl = lds;                                   // [9][32][32]
     float* tile = lds + 9 * TC * TC;                   // [72][32]
     float* sc = tile + PADCELLS * TC;                  // [32], [32]
     float* sh = sc + TC;
-    float* red = sh + TC;                              // [512]
-    __shared__ double tot[64], scratch[256];
+    float* red = sh + TC;                              // [1024]
+    __shared__ double tot[64], scratch[512];
+    __shared__ float st[96];
     const int b = blockIdx.x, tid = threadIdx.x, co = tid & 31, g = tid >> 5;
-    bn_scale_shift(bn, sc, sh);
-    for (int i = tid; i < PADCELLS * TC; i += TT) tile[i] = 0.0f;
-    for (int i = tid; i < 9 * TC * TC / 4; i += TT) reinterpret_cast<float4*>(wl)[i] = reinterpret_cast<const float4*>(wf)[i];
+    const size_t base = (size_t)b * CELLS * TC;
+    float zr[EPT], xr[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const int i = tid + j * TTC;
+        zr[j] = i < CELLS * TC ? zin[base + i] : 0.0f;
+        xr[j] = (RES && i < CELLS * TC) ? xprev[base + i] : 0.0f;
+    }
+    const WRegs wr = load_conv_weights(wf);
+    for (int i = tid; i < PADCELLS * TC; i += TTC) tile[i] = 0.0f;
+    reduce_partials(part_in, boards, tot, scratch);
+    store_conv_weights(wl, wr);
+    stats_from_totals(tot, TC, (long)boards * CELLS, eps, st, bn.stat_keep);
+    bn_scale_shift(st, bn.gamma, bn.beta, sc, sh);
     __syncthreads();
-    stage_activation<RES, WRITE_X>(tile, zin, xprev, xout, sc, sh, b);
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const int i = tid + j * TTC;
+        if (i < CELLS * TC) {
+            float a = fmaf(zr[j], sc[co], sh[co]);
+            if (RES) a += xr[j];
+            a = fmaxf(a, 0.0f);
+            if (WRITE_X) xout[base + i] = a;
+            tile[pad_index(i >> 5) * TC + co] = a;
+        }
+    }
     __syncthreads();
-    float acc[NPOS];
+    float acc[NPC];
     conv_cells<1>(tile, wl, co, g, acc);
     float s = 0.0f, q = 0.0f;
 #pragma unroll
-    for (int k = 0; k < NPOS; ++k) {
-        const int cell = g + 8 * k;
+    for (int k = 0; k < NPC; ++k) {
+        const int cell = g + 16 * k;
         if (cell < CELLS) {
-            zout[((size_t)b * CELLS + cell) * TC + co] = acc[k];
+            zout[base + cell * TC + co] = acc[k];
             s += acc[k]; q = fmaf(acc[k], acc[k], q);
         }
     }
-    board_partials(s, q, red, part + (size_t)b * 64);
-    if (last_block_totals(part, boards, counter, tot, scratch)) write_stats(tot, TC, (long)boards * CELLS, eps, stat_out);
+    board_partials(s, q, red, part_out + (size_t)b * 64);
 }
 
 // heads, first part: the tower's output X = ReLU(BN(Zin) (+ Xprev)) (stored), the three 1x1 convs (two policy
-// planes with bias, one value plane) -> zh [board][cell][4], statistics of the three planes
+// planes with bias, one value plane) -> zh [board][cell][4], the board's sums of the three planes -> part_out
 template <bool RES>
 __global__ void __launch_bounds__(TT)
-k_train_head_conv_fwd(const float* __restrict__ zin, BnRef bn, const float* __restrict__ xprev, float* __restrict__ xout,
-                      const float* __restrict__ wp, const float* __restrict__ bp, const float* __restrict__ wv,
-                      float* __restrict__ zh, float* __restrict__ part, int* counter, float* __restrict__ stat_out, int boards,
-                      float eps) {
+k_train_head_conv_fwd(const float* __restrict__ zin, const float* __restrict__ part_in, BnRef bn, const float* __restrict__ xprev,
+                      float* __restrict__ xout, const float* __restrict__ wp, const float* __restrict__ bp,
+                      const float* __restrict__ wv, float* __restrict__ zh, float* __restrict__ part_out, int boards, float eps) {
     __shared__ __attribute__((aligned(16))) float tile[PADCELLS * TC];
-    __shared__ float sc[TC], sh[TC], wh[3 * TC], red[512];
-    __shared__ double tot[64], scratch[256];
+    __shared__ float sc[TC], sh[TC], wh[3 * TC], red[512], st[96];
+    __shared__ double tot[64], scratch[512];
     const int b = blockIdx.x, tid = threadIdx.x;
-    bn_scale_shift(bn, sc, sh);
     if (tid < 2 * TC) wh[tid] = wp[tid];
     if (tid < TC) wh[2 * TC + tid] = wv[tid];
+    reduce_partials(part_in, boards, tot, scratch);
+    stats_from_totals(tot, TC, (long)boards * CELLS, eps, st, bn.stat_keep);
+    bn_scale_shift(st, bn.gamma, bn.beta, sc, sh);
     __syncthreads();
     stage_activation<RES, true>(tile, zin, xprev, xout, sc, sh, b);
     __syncthreads();
@@ -275,30 +320,36 @@ k_train_head_conv_fwd(const float* __restrict__ zin, BnRef bn, const float* __re
         zh[((size_t)b * CELLS + cell) * 4 + h] = acc;
         s = acc; q = acc * acc;
     }
-    // column sums over the 42 cells of each plane: thread (cell, h) -> red[h][cell], summed by three threads
+    // column sums over the 42 cells of each plane: thread (cell, h) -> red[h][cell], summed by six threads
     red[tid] = s; red[256 + tid] = q;
     __syncthreads();
-    if (tid < 6) {
-        const float* r = red + (tid >= 3 ? 256 : 0) + (tid % 3) * CELLS;
+    if (tid < 64) {
         float t = 0.0f;
-        for (int k = 0; k < CELLS; ++k) t += r[k];
-        part[(size_t)b * 64 + (tid >= 3 ? 32 : 0) + tid % 3] = t;
+        const int h = tid & 31;
+        if (h < 3) {
+            const float* r = red + (tid >= 32 ? 256 : 0) + h * CELLS;
+            for (int k = 0; k < CELLS; ++k) t += r[k];
+        }
+        part_out[(size_t)b * 64 + tid] = t;
     }
-    if (last_block_totals(part, boards, counter, tot, scratch)) write_stats(tot, 3, (long)boards * CELLS, eps, stat_out);
 }
 
 // heads, second part, one board per workgroup: batch-norm + ReLU of the three planes, policy FC 84 -> 42 and the
 // landing-cell gather (connectfour.py:56-71), value FC 42 -> 256 -> 1 + tanh
 __global__ void __launch_bounds__(TT)
-k_train_head_fc_fwd(const float* __restrict__ x, const float* __restrict__ zh, const float* __restrict__ stat_h,
-                    const float* __restrict__ gp, const float* __restrict__ btp, const float* __restrict__ gv,
-                    const float* __restrict__ btv, const float* __restrict__ wpf, const float* __restrict__ bpf,
-                    const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
-                    const float* __restrict__ b2, float* __restrict__ hplanes /* [board][128]: 84 policy, 42 value */,
-                    float* __restrict__ h1 /* [board][256] */, float* __restrict__ logits7, float* __restrict__ vhat) {
-    __shared__ float hp[128], cl[CELLS], red[TT];
+k_train_head_fc_fwd(const float* __restrict__ x, const float* __restrict__ zh, const float* __restrict__ part_in,
+                    float* __restrict__ stat_h_keep, const float* __restrict__ gp, const float* __restrict__ btp,
+                    const float* __restrict__ gv, const float* __restrict__ btv, const float* __restrict__ wpf,
+                    const float* __restrict__ bpf, const float* __restrict__ w1, const float* __restrict__ b1,
+                    const float* __restrict__ w2, const float* __restrict__ b2,
+                    float* __restrict__ hplanes /* [board][128]: 84 policy, 42 value */, float* __restrict__ h1 /* [board][256] */,
+                    float* __restrict__ logits7, float* __restrict__ vhat, int boards, float eps) {
+    __shared__ float hp[128], cl[CELLS], red[TT], stat_h[96];
     __shared__ int height[8];
+    __shared__ double tot[64], scratch[512];
     const int b = blockIdx.x, tid = threadIdx.x;
+    reduce_partials(part_in, boards, tot, scratch);
+    stats_from_totals(tot, 3, (long)boards * CELLS, eps, stat_h, stat_h_keep);
     if (tid < 3 * CELLS) {
         const int cell = tid % CELLS, h = tid / CELLS;
         const float gamma = h < 2 ? gp[h] : gv[0], beta = h < 2 ? btp[h] : btv[0];
@@ -351,12 +402,9 @@ k_train_head_fc_bwd(const float* __restrict__ x, const float* __restrict__ dlogi
                     const float* __restrict__ vhat, const float* __restrict__ h1, const float* __restrict__ hplanes,
                     const float* __restrict__ zh, const float* __restrict__ stat_h, const float* __restrict__ wpf,
                     const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ dh1, float* __restrict__ dpre2,
-                    float* __restrict__ dcl, float* __restrict__ dyh, float* __restrict__ part, int* counter,
-                    float* __restrict__ sums_h, float* __restrict__ g_gp, float* __restrict__ g_btp, float* __restrict__ g_gv,
-                    float* __restrict__ g_btv, int boards) {
+                    float* __restrict__ dcl, float* __restrict__ dyh, float* __restrict__ part_out) {
     __shared__ float d1[TT], dcl_s[CELLS], red[512];
     __shared__ int height[8];
-    __shared__ double tot[64], scratch[256];
     const int b = blockIdx.x, tid = threadIdx.x;
     const float v = vhat[b];
     const float dp = dv[b] * (1.0f - v * v);
@@ -396,100 +444,136 @@ k_train_head_fc_bwd(const float* __restrict__ x, const float* __restrict__ dlogi
     }
     red[tid] = s1; red[256 + tid] = s2;
     __syncthreads();
-    if (tid < 6) {
-        const float* r = red + (tid >= 3 ? 256 : 0) + (tid % 3) * CELLS;
+    if (tid < 64) {
         float t = 0.0f;
-        for (int k = 0; k < CELLS; ++k) t += r[k];
-        part[(size_t)b * 64 + (tid >= 3 ? 32 : 0) + tid % 3] = t;
-    }
-    if (last_block_totals(part, boards, counter, tot, scratch)) {
-        if (tid < 3) {
-            sums_h[tid] = (float)tot[tid];
-            sums_h[32 + tid] = (float)tot[32 + tid];
-            // the head batch-norms' own gradients: d beta = sum dy, d gamma = sum dy * x-hat
-            if (tid < 2) { g_btp[tid] = (float)tot[tid]; g_gp[tid] = (float)tot[32 + tid]; }
-            else { g_btv[0] = (float)tot[2]; g_gv[0] = (float)tot[34]; }
+        const int h = tid & 31;
+        if (h < 3) {
+            const float* r = red + (tid >= 32 ? 256 : 0) + h * CELLS;
+            for (int k = 0; k < CELLS; ++k) t += r[k];
         }
+        part_out[(size_t)b * 64 + tid] = t;
     }
 }
 
-// weight gradients of the fully connected layers: one thread per weight, a sum over the batch in board order
+// Sum over the batch by a workgroup of 256 threads for 64 outputs: thread (output = tid & 63, part = tid >> 6) adds
+// the boards part, part + 4, ... (eight loads in flight), the four parts are added in order.  f(board) = the term.
+template <class F>
+__device__ __forceinline__ float batch_sum(int boards, float* red /* LDS [256] */, F f) {
+    const int q = threadIdx.x >> 6;
+    float s = 0.0f;
+    for (int b0 = q; b0 < boards; b0 += 32) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = b0 + 4 * j < boards ? f(b0 + 4 * j) : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    return red[threadIdx.x & 63] + red[64 + (threadIdx.x & 63)] + red[128 + (threadIdx.x & 63)] + red[192 + (threadIdx.x & 63)];
+}
+
+// weight gradients of the fully connected layers: sums over the batch, 64 weights per workgroup
 __global__ void __launch_bounds__(TT)
 k_train_fc_wgrad(const float* __restrict__ dh1, const float* __restrict__ dpre2, const float* __restrict__ dcl,
                  const float* __restrict__ h1, const float* __restrict__ hplanes, int boards, float* __restrict__ g_w1,
                  float* __restrict__ g_b1, float* __restrict__ g_w2, float* __restrict__ g_b2, float* __restrict__ g_wpf,
                  float* __restrict__ g_bpf) {
-    int i = blockIdx.x * TT + threadIdx.x;
-    float s = 0.0f;
+    __shared__ float red[TT];
+    int i = blockIdx.x * 64 + (threadIdx.x & 63);
+    const bool writer = threadIdx.x < 64;
+    // (each range below is a multiple of 64 long or the last one, so a workgroup never straddles two of them)
     if (i < 256 * CELLS) {
         const int j = i / CELLS, c = i % CELLS;
-        for (int b = 0; b < boards; ++b) s = fmaf(dh1[(size_t)b * 256 + j], hplanes[(size_t)b * 128 + 84 + c], s);
-        g_w1[i] = s;
+        const float s = batch_sum(boards, red, [&](int b) { return dh1[(size_t)b * 256 + j] * hplanes[(size_t)b * 128 + 84 + c]; });
+        if (writer) g_w1[i] = s;
         return;
     }
     i -= 256 * CELLS;
-    if (i < 256) { for (int b = 0; b < boards; ++b) s += dh1[(size_t)b * 256 + i]; g_b1[i] = s; return; }
-    i -= 256;
-    if (i < 256) { for (int b = 0; b < boards; ++b) s = fmaf(dpre2[b], h1[(size_t)b * 256 + i], s); g_w2[i] = s; return; }
-    i -= 256;
-    if (i < 1) { for (int b = 0; b < boards; ++b) s += dpre2[b]; g_b2[0] = s; return; }
-    i -= 1;
-    if (i < CELLS * 84) {
-        const int cell = i / 84, k = i % 84;
-        for (int b = 0; b < boards; ++b) s = fmaf(dcl[(size_t)b * CELLS + cell], hplanes[(size_t)b * 128 + k], s);
-        g_wpf[i] = s;
+    if (i < 256) {
+        const float s = batch_sum(boards, red, [&](int b) { return dh1[(size_t)b * 256 + i]; });
+        if (writer) g_b1[i] = s;
         return;
     }
-    i -= CELLS * 84;
-    if (i < CELLS) { for (int b = 0; b < boards; ++b) s += dcl[(size_t)b * CELLS + i]; g_bpf[i] = s; }
+    i -= 256;
+    if (i < 256) {
+        const float s = batch_sum(boards, red, [&](int b) { return dpre2[b] * h1[(size_t)b * 256 + i]; });
+        if (writer) g_w2[i] = s;
+        return;
+    }
+    i -= 256;
+    if (i < 64) {                                          // one output: the value head's last bias
+        const float s = batch_sum(boards, red, [&](int b) { return i == 0 ? dpre2[b] : 0.0f; });
+        if (writer && i == 0) g_b2[0] = s;
+        return;
+    }
+    i -= 64;
+    if (i < 56 * 64) {                                     // 3528 weights in 56 workgroups (the last one partly idle)
+        const bool in = i < CELLS * 84;
+        const int cell = in ? i / 84 : 0, k = in ? i % 84 : 0;
+        const float s = batch_sum(boards, red, [&](int b) { return dcl[(size_t)b * CELLS + cell] * hplanes[(size_t)b * 128 + k]; });
+        if (writer && in) g_wpf[i] = s;
+        return;
+    }
+    i -= 56 * 64;
+    {
+        const bool in = i >= 0 && i < CELLS;
+        const int cell = in ? i : 0;
+        const float s = batch_sum(boards, red, [&](int b) { return dcl[(size_t)b * CELLS + cell]; });
+        if (writer && in) g_bpf[cell] = s;
+    }
 }
+#define FC_WGRAD_GROUPS (256 * CELLS / 64 + 4 + 4 + 1 + 56 + 1)
 
-// batch-norm backward coefficients of a layer from its statistics and the batch sums of its incoming gradient:
+// batch-norm backward coefficients of a layer from its saved statistics and the batch sums of its incoming gradient
+// (tot: sum dy, sum dy * xhat, just added up from the previous launch's partial sums):
 // dz = k1 * (dy - m1 - xhat * m2), xhat = (z - mean) * invstd
-struct BnBack { const float* stat; const float* gamma; const float* sums; };
-__device__ __forceinline__ void bn_back_coeff(const BnBack& bb, int nch, float inv_n, float* k1, float* m1, float* m2,
-                                              float* mean, float* invstd) {
+struct BnBack { const float* stat; const float* gamma; };
+__device__ __forceinline__ void bn_back_coeff(const BnBack& bb, const double* tot, int nch, float inv_n, float* k1, float* m1,
+                                              float* m2, float* mean, float* invstd) {
     if ((int)threadIdx.x < nch) {
         const int c = threadIdx.x;
         mean[c] = bb.stat[c];
         invstd[c] = bb.stat[32 + c];
         k1[c] = bb.gamma[c] * bb.stat[32 + c];
-        m1[c] = bb.sums[c] * inv_n;
-        m2[c] = bb.sums[32 + c] * inv_n;
+        m1[c] = (float)tot[c] * inv_n;
+        m2[c] = (float)tot[32 + c] * inv_n;
     }
 }
-
-// Accumulates the sums of a batch-norm's backward into that batch-norm's gradient accumulators (the shared block's
-// batch-norms are applied num_blocks times) and leaves them for the next launch.
-__device__ __forceinline__ void publish_bn_sums(const double* tot, float* sums_out, float* bn_acc /* [64]: d beta, d gamma */) {
-    if (threadIdx.x < 64) {
-        sums_out[threadIdx.x] = (float)tot[threadIdx.x];
-        bn_acc[threadIdx.x] += (float)tot[threadIdx.x];
-    }
+// the same sums are that batch-norm's own gradients (d beta = sum dy, d gamma = sum dy * xhat): workgroup 0 adds them
+// to the batch-norm's accumulators (the shared block's batch-norms are applied num_blocks times)
+__device__ __forceinline__ void accumulate_bn_grad(const double* tot, float* bn_acc /* [64] */) {
+    if (blockIdx.x == 0 && threadIdx.x < 64) bn_acc[threadIdx.x] += (float)tot[threadIdx.x];
 }
 
 // heads, last part of the backward: dzh from dyh, the gradient at the tower's output X (three planes back through
 // the 1x1 convs), its ReLU mask -> dU [board][cell][32], partial sums of the last tower batch-norm's backward
 // (x-hat from zprev), and the board's share of the 1x1 convs' weight and bias gradients -> pwh [board][128]
 __global__ void __launch_bounds__(TT)
-k_train_head_conv_bwd(const float* __restrict__ dyh, const float* __restrict__ zh, BnBack hb /* gamma unused */,
-                      const float* __restrict__ gp, const float* __restrict__ gv, const float* __restrict__ wp,
-                      const float* __restrict__ wv, const float* __restrict__ xtop, const float* __restrict__ zprev,
-                      const float* __restrict__ stat_prev, float* __restrict__ du, float* __restrict__ pwh,
-                      float* __restrict__ part, int* counter, float* __restrict__ sums_prev, float* __restrict__ bn_acc_prev,
-                      int boards) {
+k_train_head_conv_bwd(const float* __restrict__ dyh, const float* __restrict__ zh, const float* __restrict__ stat_h,
+                      const float* __restrict__ part_in, const float* __restrict__ gp, const float* __restrict__ gv,
+                      float* __restrict__ g_gp, float* __restrict__ g_btp, float* __restrict__ g_gv, float* __restrict__ g_btv,
+                      const float* __restrict__ wp, const float* __restrict__ wv, const float* __restrict__ xtop,
+                      const float* __restrict__ zprev, const float* __restrict__ stat_prev, float* __restrict__ du,
+                      float* __restrict__ pwh, float* __restrict__ part_out, int boards) {
     __shared__ float dz[CELLS * 4], wh[3 * TC], red[512];
-    __shared__ double tot[64], scratch[256];
+    __shared__ double tot[64], scratch[512];
     const int b = blockIdx.x, tid = threadIdx.x, ci = tid & 31, g = tid >> 5;
     const float inv_n = 1.0f / (float)((long)boards * CELLS);
     if (tid < 2 * TC) wh[tid] = wp[tid];
     if (tid < TC) wh[2 * TC + tid] = wv[tid];
+    reduce_partials(part_in, boards, tot, scratch);
+    if (b == 0 && tid < 3) {
+        // the head batch-norms' own gradients: d beta = sum dy, d gamma = sum dy * x-hat
+        if (tid < 2) { g_btp[tid] = (float)tot[tid]; g_gp[tid] = (float)tot[32 + tid]; }
+        else { g_btv[0] = (float)tot[2]; g_gv[0] = (float)tot[34]; }
+    }
     if (tid < 3 * CELLS) {
         const int cell = tid % CELLS, h = tid / CELLS;
         const float gamma = h < 2 ? gp[h] : gv[0];
-        const float xh = (zh[((size_t)b * CELLS + cell) * 4 + h] - hb.stat[h]) * hb.stat[32 + h];
-        dz[cell * 4 + h] = gamma * hb.stat[32 + h] *
-                           (dyh[((size_t)b * CELLS + cell) * 4 + h] - hb.sums[h] * inv_n - xh * hb.sums[32 + h] * inv_n);
+        const float xh = (zh[((size_t)b * CELLS + cell) * 4 + h] - stat_h[h]) * stat_h[32 + h];
+        dz[cell * 4 + h] = gamma * stat_h[32 + h] *
+                           (dyh[((size_t)b * CELLS + cell) * 4 + h] - (float)tot[h] * inv_n - xh * ((float)tot[32 + h] * inv_n));
     }
     __syncthreads();
     float s1 = 0.0f, s2 = 0.0f;
@@ -517,13 +601,14 @@ k_train_head_conv_bwd(const float* __restrict__ dyh, const float* __restrict__ z
         pwh[(size_t)b * 128 + tid] = w;
         if (ci == 0) pwh[(size_t)b * 128 + 96 + h] = bsum;
     }
-    board_partials(s1, s2, red, part + (size_t)b * 64);
-    if (last_block_totals(part, boards, counter, tot, scratch)) publish_bn_sums(tot, sums_prev, bn_acc_prev);
+    board_partials(s1, s2, red, part_out + (size_t)b * 64);
 }
 
 // Backward of one 3x3 conv layer of the tower, one board per workgroup.
-//   dyout, zout, ob   gradient at this layer's batch-norm output (ReLU mask applied), its conv output, its batch-norm
-//   A (this conv's input): MODE_T: ReLU(BN_in(zin)), recomputed; else the stored block input xin
+//   dyout, zout, ob   gradient at this layer's batch-norm output (ReLU mask applied), its conv output, its batch-norm;
+//   part_in           the boards' sums of dyout, dyout * xhat from the launch before; bn_acc_out: that batch-norm's
+//                     gradient accumulators
+//   A (this conv's input): MODE_T: ReLU(BN_in(zin)) with BN_in's saved statistics, recomputed; else the stored xin
 //   wb                this conv's weights as [tap][co][ci]
 //   res               (RES) added to the input gradient before the mask: the gradient that reaches the block input
 //                     through the residual connection
@@ -532,12 +617,13 @@ k_train_head_conv_bwd(const float* __restrict__ dyh, const float* __restrict__ z
 //   pw                the board's share of this conv's weight gradient [tap][ci][co]; ACCUM: added to what an earlier
 //                     application of the shared block left there
 template <bool MODE_T, bool RES, bool ACCUM>
-__global__ void __launch_bounds__(TT)
-k_train_conv_bwd(const float* __restrict__ dyout, const float* __restrict__ zout, BnBack ob, const float* __restrict__ zin,
-                 BnRef bn_in, const float* __restrict__ xin, const float* __restrict__ wb, const float* res /* may be dyprev */,
-                 float* dyprev, const float* __restrict__ zprev, const float* __restrict__ stat_prev,
-                 float* __restrict__ pw, float* __restrict__ part, int* counter, float* __restrict__ sums_prev,
-                 float* __restrict__ bn_acc_prev, int boards) {
+__global__ void __launch_bounds__(TTC)
+k_train_conv_bwd(const float* __restrict__ dyout, const float* __restrict__ zout, BnBack ob, const float* __restrict__ part_in,
+                 float* __restrict__ bn_acc_out, const float* __restrict__ zin, const float* __restrict__ stat_in,
+                 const float* __restrict__ gamma_in, const float* __restrict__ beta_in, const float* __restrict__ xin,
+                 const float* __restrict__ wb, const float* res /* may be dyprev */, float* dyprev,
+                 const float* __restrict__ zprev, const float* __restrict__ stat_prev, float* __restrict__ pw,
+                 float* __restrict__ part_out, int boards) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wl = lds;                                   // [9][32 co][32 ci]
     float* dzt = lds + 9 * TC * TC;                    // [72][32] dZ
@@ -549,83 +635,104 @@ k_train_conv_bwd(const float* __restrict__ dyout, const float* __restrict__ zout
     float* m2 = m1 + TC;
     float* mean = m2 + TC;
     float* invstd = mean + TC;
-    float* red = invstd + TC;                          // [512]
-    __shared__ double tot[64], scratch[256];
+    float* red = invstd + TC;                          // [1024]
+    __shared__ double tot[64], scratch[512];
     const int b = blockIdx.x, tid = threadIdx.x, lane32 = tid & 31, g = tid >> 5;
     const float inv_n = 1.0f / (float)((long)boards * CELLS);
-    bn_back_coeff(ob, TC, inv_n, k1, m1, m2, mean, invstd);
-    if (MODE_T) bn_scale_shift(bn_in, sc, sh);
-    for (int i = tid; i < 2 * PADCELLS * TC; i += TT) dzt[i] = 0.0f;          // both tiles
-    for (int i = tid; i < 9 * TC * TC / 4; i += TT) reinterpret_cast<float4*>(wl)[i] = reinterpret_cast<const float4*>(wb)[i];
+    const size_t base = (size_t)b * CELLS * TC;
+    // every global load of the launch, before the first wait (element tid + 512 j = (cell g + 16 j, channel lane32):
+    // the cells this thread also computes the input gradient of)
+    float dyr[EPT], zor[EPT], ar[EPT], rr[EPT], zpr[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const int i = tid + j * TTC;
+        const bool in = i < CELLS * TC;
+        dyr[j] = in ? dyout[base + i] : 0.0f;
+        zor[j] = in ? zout[base + i] : 0.0f;
+        ar[j] = in ? (MODE_T ? zin[base + i] : xin[base + i]) : 0.0f;
+        rr[j] = (RES && in) ? res[base + i] : 0.0f;
+        zpr[j] = in ? (MODE_T ? ar[j] : zprev[base + i]) : 0.0f;       // MODE_T: the previous batch-norm's input is zin
+    }
+    const WRegs wr = load_conv_weights(wb);
+    const float sp_mean = stat_prev[lane32], sp_inv = stat_prev[32 + lane32];
+    for (int i = tid; i < 2 * PADCELLS * TC; i += TTC) dzt[i] = 0.0f;         // both tiles
+    reduce_partials(part_in, boards, tot, scratch);
+    store_conv_weights(wl, wr);
+    bn_back_coeff(ob, tot, TC, inv_n, k1, m1, m2, mean, invstd);
+    accumulate_bn_grad(tot, bn_acc_out);
+    if (MODE_T) bn_scale_shift(stat_in, gamma_in, beta_in, sc, sh);
     __syncthreads();
-    for (int i = tid; i < CELLS * TC; i += TT) {
-        const int cell = i >> 5, c = i & 31;
-        const size_t gi = (size_t)b * CELLS * TC + i;
-        const float xh = (zout[gi] - mean[c]) * invstd[c];
-        dzt[pad_index(cell) * TC + c] = k1[c] * (dyout[gi] - m1[c] - xh * m2[c]);
-        at[pad_index(cell) * TC + c] = MODE_T ? fmaxf(fmaf(zin[gi], sc[c], sh[c]), 0.0f) : xin[gi];
+    float a_own[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const int i = tid + j * TTC;
+        a_own[j] = 0.0f;
+        if (i < CELLS * TC) {
+            const int pi = pad_index(i >> 5);
+            const float xh = (zor[j] - mean[lane32]) * invstd[lane32];
+            dzt[pi * TC + lane32] = k1[lane32] * (dyr[j] - m1[lane32] - xh * m2[lane32]);
+            a_own[j] = MODE_T ? fmaxf(fmaf(ar[j], sc[lane32], sh[lane32]), 0.0f) : ar[j];
+            at[pi * TC + lane32] = a_own[j];
+        }
     }
     __syncthreads();
-    // ---- the board's share of the weight gradient: thread (co, four input channels), nine taps
+    // ---- the board's share of the weight gradient: thread (co, two input channels), nine taps
     {
         const int co = lane32, cg = g;
-        float acc[9][4];
+        float acc[9][2];
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[t][j] = 0.0f;
-#pragma unroll 1
+        for (int t = 0; t < 9; ++t) { acc[t][0] = 0.0f; acc[t][1] = 0.0f; }
+#pragma unroll 2
         for (int cell = 0; cell < CELLS; ++cell) {
             const int pi = pad_index(cell);
             const float d = dzt[pi * TC + co];
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const float4 a = *reinterpret_cast<const float4*>(at + (pi + tap_offset(t)) * TC + 4 * cg);
+                const float2 a = *reinterpret_cast<const float2*>(at + (pi + tap_offset(t)) * TC + 2 * cg);
                 acc[t][0] = fmaf(a.x, d, acc[t][0]);
                 acc[t][1] = fmaf(a.y, d, acc[t][1]);
-                acc[t][2] = fmaf(a.z, d, acc[t][2]);
-                acc[t][3] = fmaf(a.w, d, acc[t][3]);
             }
         }
         float* out = pw + (size_t)b * 9 * TC * TC;
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int idx = (t * TC + 4 * cg + j) * TC + co;
+            for (int j = 0; j < 2; ++j) {
+                const int idx = (t * TC + 2 * cg + j) * TC + co;
                 out[idx] = ACCUM ? out[idx] + acc[t][j] : acc[t][j];
             }
     }
-    // ---- input gradient, mask, the previous batch-norm's sums: thread (ci, six cells)
-    float acc[NPOS];
+    // ---- input gradient, mask, the previous batch-norm's sums: thread (ci, three cells)
+    float acc[NPC];
     conv_cells<-1>(dzt, wl, lane32, g, acc);
     float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
-    for (int k = 0; k < NPOS; ++k) {
-        const int cell = g + 8 * k;
+    for (int k = 0; k < NPC; ++k) {
+        const int cell = g + 16 * k;
         if (cell < CELLS) {
-            const size_t gi = ((size_t)b * CELLS + cell) * TC + lane32;
             float d = acc[k];
-            if (RES) d += res[gi];
-            if (!(at[pad_index(cell) * TC + lane32] > 0.0f)) d = 0.0f;
-            dyprev[gi] = d;
-            const float xh = (zprev[gi] - stat_prev[lane32]) * stat_prev[32 + lane32];
+            if (RES) d += rr[k];
+            if (!(a_own[k] > 0.0f)) d = 0.0f;
+            dyprev[base + cell * TC + lane32] = d;
+            const float xh = (zpr[k] - sp_mean) * sp_inv;
             s1 += d; s2 = fmaf(d, xh, s2);
         }
     }
-    board_partials(s1, s2, red, part + (size_t)b * 64);
-    if (last_block_totals(part, boards, counter, tot, scratch)) publish_bn_sums(tot, sums_prev, bn_acc_prev);
+    board_partials(s1, s2, red, part_out + (size_t)b * 64);
 }
 
 // stem backward: dZ0 from the gradient at the stem batch-norm's output; the board's share of the stem conv's weight
 // gradient -> pws [board][18][32] (index (tap * 2 + plane) * 32 + co)
 __global__ void __launch_bounds__(TT)
 k_train_stem_bwd(const float* __restrict__ x, const float* __restrict__ dy0, const float* __restrict__ z0, BnBack ob,
-                 float* __restrict__ pws, int boards) {
+                 const float* __restrict__ part_in, float* __restrict__ bn_acc_out, float* __restrict__ pws, int boards) {
     __shared__ float xt[PADCELLS * 2], dzt[CELLS * TC], k1[TC], m1[TC], m2[TC], mean[TC], invstd[TC];
+    __shared__ double tot[64], scratch[512];
     const int b = blockIdx.x, tid = threadIdx.x, co = tid & 31, g = tid >> 5;
     const float inv_n = 1.0f / (float)((long)boards * CELLS);
-    bn_back_coeff(ob, TC, inv_n, k1, m1, m2, mean, invstd);
+    reduce_partials(part_in, boards, tot, scratch);
+    bn_back_coeff(ob, tot, TC, inv_n, k1, m1, m2, mean, invstd);
+    accumulate_bn_grad(tot, bn_acc_out);
     for (int i = tid; i < PADCELLS * 2; i += TT) xt[i] = 0.0f;
     __syncthreads();
     for (int i = tid; i < 2 * CELLS; i += TT) xt[pad_index(i % CELLS) * 2 + i / CELLS] = x[(size_t)b * 84 + i];
@@ -659,39 +766,38 @@ k_train_finish(const float* __restrict__ pw1, const float* __restrict__ pw2, con
                float* __restrict__ g_bn1_w, float* __restrict__ g_bn1_b, float* __restrict__ g_bn2_w, float* __restrict__ g_bn2_b,
                const float* __restrict__ stats /* [2 * blocks + 1][96] */, const float* __restrict__ stat_h, RunStat r0, RunStat r1,
                RunStat r2, RunStat rp, RunStat rv, float momentum) {
-    int i = blockIdx.x * TT + threadIdx.x;
+    __shared__ float red[TT];
+    int i = blockIdx.x * 64 + (threadIdx.x & 63);
+    const bool writer = threadIdx.x < 64;
     const long n = (long)boards * CELLS;
     if (i < 2 * 9 * TC * TC) {
         const bool second = i >= 9 * TC * TC;
         const int j = second ? i - 9 * TC * TC : i;                 // [tap][ci][co]
         const float* p = (second ? pw2 : pw1) + j;
-        float s = 0.0f;
-        if (num_blocks > 0)
-            for (int b = 0; b < boards; ++b) s += p[(size_t)b * 9 * TC * TC];
+        const float s = batch_sum(num_blocks > 0 ? boards : 0, red, [&](int b) { return p[(size_t)b * 9 * TC * TC]; });
         const int tap = j / (TC * TC), ci = (j / TC) % TC, co = j % TC;
-        (second ? g_c2 : g_c1)[(co * TC + ci) * 9 + tap] = s;
+        if (writer) (second ? g_c2 : g_c1)[(co * TC + ci) * 9 + tap] = s;
         return;
     }
     i -= 2 * 9 * TC * TC;
     if (i < 18 * TC) {
-        float s = 0.0f;
-        for (int b = 0; b < boards; ++b) s += pws[(size_t)b * 18 * TC + i];
+        const float s = batch_sum(boards, red, [&](int b) { return pws[(size_t)b * 18 * TC + i]; });
         const int tap = i / (2 * TC), plane = (i / TC) % 2, co = i % TC;
-        g_stem[(co * 2 + plane) * 9 + tap] = s;
+        if (writer) g_stem[(co * 2 + plane) * 9 + tap] = s;
         return;
     }
     i -= 18 * TC;
     if (i < 128) {
-        float s = 0.0f;
-        if (i < 99)
-            for (int b = 0; b < boards; ++b) s += pwh[(size_t)b * 128 + i];
-        if (i < 2 * TC) g_wp[i] = s;
-        else if (i < 3 * TC) g_wv[i - 2 * TC] = s;
-        else if (i < 98 && i >= 96) g_bp[i - 96] = s;
+        const float s = batch_sum(boards, red, [&](int b) { return i < 99 ? pwh[(size_t)b * 128 + i] : 0.0f; });
+        if (writer) {
+            if (i < 2 * TC) g_wp[i] = s;
+            else if (i < 3 * TC) g_wv[i - 2 * TC] = s;
+            else if (i >= 96 && i < 98) g_bp[i - 96] = s;
+        }
         return;
     }
     i -= 128;
-    if (i < TC) {
+    if (threadIdx.x < TC && i < TC) {
         const int c = i;
         g_bn0_b[c] = bn_acc[c];           g_bn0_w[c] = bn_acc[32 + c];
         g_bn1_b[c] = bn_acc[64 + c];      g_bn1_w[c] = bn_acc[64 + 32 + c];
@@ -720,6 +826,7 @@ k_train_finish(const float* __restrict__ pw1, const float* __restrict__ pw2, con
         }
     }
 }
+#define FINISH_GROUPS ((2 * 9 * TC * TC + 18 * TC + 128) / 64 + 1)
 
 // ---------------------------------------------------------------------------------------------------------
 // host side
@@ -728,7 +835,7 @@ namespace {
 struct Ws {                        // the workspace, in floats
     size_t act;                    // one activation tensor [boards][42][32]
     size_t z, x, g0, g1, zh, dyh, hplanes, h1, dh1, dpre2, dcl, logits7, vhat, dlogits7, dv, out3, part, stats, stat_h,
-        sums, sums_h, bn_acc, wf1, wb1, wf2, wb2, ws, pw1, pw2, pws, pwh, counter, total;
+        part2, bn_acc, wf1, wb1, wf2, wb2, ws, pw1, pw2, pws, pwh, total;
 };
 Ws layout(int boards, int blocks) {
     Ws w;
@@ -754,8 +861,7 @@ Ws layout(int boards, int blocks) {
     w.part = take((size_t)boards * 64);
     w.stats = take((size_t)(2 * blocks + 1) * 96);
     w.stat_h = take(96);
-    w.sums = take(64);
-    w.sums_h = take(64);
+    w.part2 = take((size_t)boards * 64);
     w.bn_acc = take(3 * 64);
     w.wf1 = take(9 * TC * TC); w.wb1 = take(9 * TC * TC); w.wf2 = take(9 * TC * TC); w.wb2 = take(9 * TC * TC);
     w.ws = take(18 * TC);
@@ -763,12 +869,11 @@ Ws layout(int boards, int blocks) {
     w.pw2 = take((size_t)boards * 9 * TC * TC);
     w.pws = take((size_t)boards * 18 * TC);
     w.pwh = take((size_t)boards * 128);
-    w.counter = take(64);
     w.total = o;
     return w;
 }
-constexpr int FWD_LDS = (9 * TC * TC + PADCELLS * TC + 2 * TC + 512) * 4;
-constexpr int BWD_LDS = (9 * TC * TC + 2 * PADCELLS * TC + 7 * TC + 512) * 4;
+constexpr int FWD_LDS = (9 * TC * TC + PADCELLS * TC + 2 * TC + 1024) * 4;
+constexpr int BWD_LDS = (9 * TC * TC + 2 * PADCELLS * TC + 7 * TC + 1024) * 4;
 std::atomic<unsigned long long> g_attr[8];
 template <class K> int big_lds(K kernel, int bytes, int slot) {
     return az_set_kernel_lds(reinterpret_cast<const void*>(kernel), bytes, g_attr[slot]);
@@ -796,8 +901,12 @@ int az_c4_train_fwd_bwd(const az_c4_train_net* net, const float* x, const uint8_
     float* Z = W + w.z;
     float* X = W + w.x;
     float* stats = W + w.stats;
-    float* part = W + w.part;
-    int* counter = reinterpret_cast<int*>(W + w.counter);
+    // the boards' partial sums go from each launch to the next through two buffers used in turn
+    float* parts[2] = {W + w.part, W + w.part2};
+    int turn = 0;
+    auto Pout = [&]() { return parts[turn]; };
+    auto Pin = [&]() { return parts[turn ^ 1]; };
+    auto next = [&]() { turn ^= 1; };
     auto Zl = [&](int l) { return Z + (size_t)l * w.act; };
     auto Xk = [&](int k) { return X + (size_t)k * w.act; };
     auto St = [&](int l) { return stats + (size_t)l * 96; };
@@ -810,35 +919,41 @@ int az_c4_train_fwd_bwd(const az_c4_train_net* net, const float* x, const uint8_
     if (int rc = big_lds(k_train_conv_bwd<false, true, true>, BWD_LDS, 6)) return rc;
 
     const BnRef bn0{St(0), net->stem_bn.weight, net->stem_bn.bias};
+    const float* nof = nullptr;
     // ---- forward
     hipLaunchKernelGGL(k_train_prep, dim3((9 * TC * TC + TT - 1) / TT), dim3(TT), 0, st, net->c1_w, net->c2_w, net->stem_w,
-                       W + w.wf1, W + w.wb1, W + w.wf2, W + w.wb2, W + w.ws, W + w.bn_acc, counter);
-    hipLaunchKernelGGL(k_train_stem_fwd, dim3(B), dim3(TT), 0, st, x, W + w.ws, Zl(0), part, counter, St(0), B, eps);
+                       W + w.wf1, W + w.wb1, W + w.wf2, W + w.wb2, W + w.ws, W + w.bn_acc);
+    hipLaunchKernelGGL(k_train_stem_fwd, dim3(B), dim3(TT), 0, st, x, W + w.ws, Zl(0), Pout());
+    next();
     for (int k = 0; k < nb; ++k) {
         const BnRef bn1{St(1 + 2 * k), net->bn1.weight, net->bn1.bias};
         if (k == 0)
-            hipLaunchKernelGGL((k_train_conv_fwd<false, true>), dim3(B), dim3(TT), FWD_LDS, st, Zl(0), bn0, (const float*)nullptr,
-                               Xk(0), W + w.wf1, Zl(1), part, counter, St(1), B, eps);
+            hipLaunchKernelGGL((k_train_conv_fwd<false, true>), dim3(B), dim3(TTC), FWD_LDS, st, Zl(0), Pin(), bn0, nof, Xk(0),
+                               W + w.wf1, Zl(1), Pout(), B, eps);
         else {
             const BnRef bn2p{St(2 * k), net->bn2.weight, net->bn2.bias};
-            hipLaunchKernelGGL((k_train_conv_fwd<true, true>), dim3(B), dim3(TT), FWD_LDS, st, Zl(2 * k), bn2p,
-                               (const float*)Xk(k - 1), Xk(k), W + w.wf1, Zl(1 + 2 * k), part, counter, St(1 + 2 * k), B, eps);
+            hipLaunchKernelGGL((k_train_conv_fwd<true, true>), dim3(B), dim3(TTC), FWD_LDS, st, Zl(2 * k), Pin(), bn2p,
+                               (const float*)Xk(k - 1), Xk(k), W + w.wf1, Zl(1 + 2 * k), Pout(), B, eps);
         }
-        hipLaunchKernelGGL((k_train_conv_fwd<false, false>), dim3(B), dim3(TT), FWD_LDS, st, Zl(1 + 2 * k), bn1,
-                           (const float*)nullptr, (float*)nullptr, W + w.wf2, Zl(2 + 2 * k), part, counter, St(2 + 2 * k), B, eps);
+        next();
+        hipLaunchKernelGGL((k_train_conv_fwd<false, false>), dim3(B), dim3(TTC), FWD_LDS, st, Zl(1 + 2 * k), Pin(), bn1, nof,
+                           (float*)nullptr, W + w.wf2, Zl(2 + 2 * k), Pout(), B, eps);
+        next();
     }
     if (nb == 0)
-        hipLaunchKernelGGL((k_train_head_conv_fwd<false>), dim3(B), dim3(TT), 0, st, Zl(0), bn0, (const float*)nullptr, Xk(0),
-                           net->pol_conv_w, net->pol_conv_b, net->val_conv_w, W + w.zh, part, counter, W + w.stat_h, B, eps);
+        hipLaunchKernelGGL((k_train_head_conv_fwd<false>), dim3(B), dim3(TT), 0, st, Zl(0), Pin(), bn0, nof, Xk(0),
+                           net->pol_conv_w, net->pol_conv_b, net->val_conv_w, W + w.zh, Pout(), B, eps);
     else {
         const BnRef bn2l{St(2 * nb), net->bn2.weight, net->bn2.bias};
-        hipLaunchKernelGGL((k_train_head_conv_fwd<true>), dim3(B), dim3(TT), 0, st, Zl(2 * nb), bn2l, (const float*)Xk(nb - 1),
-                           Xk(nb), net->pol_conv_w, net->pol_conv_b, net->val_conv_w, W + w.zh, part, counter, W + w.stat_h,
+        hipLaunchKernelGGL((k_train_head_conv_fwd<true>), dim3(B), dim3(TT), 0, st, Zl(2 * nb), Pin(), bn2l,
+                           (const float*)Xk(nb - 1), Xk(nb), net->pol_conv_w, net->pol_conv_b, net->val_conv_w, W + w.zh, Pout(),
                            B, eps);
     }
-    hipLaunchKernelGGL(k_train_head_fc_fwd, dim3(B), dim3(TT), 0, st, x, W + w.zh, W + w.stat_h, net->pol_bn.weight,
+    next();
+    hipLaunchKernelGGL(k_train_head_fc_fwd, dim3(B), dim3(TT), 0, st, x, W + w.zh, Pin(), W + w.stat_h, net->pol_bn.weight,
                        net->pol_bn.bias, net->val_bn.weight, net->val_bn.bias, net->pol_fc_w, net->pol_fc_b, net->val_fc1_w,
-                       net->val_fc1_b, net->val_fc2_w, net->val_fc2_b, W + w.hplanes, W + w.h1, W + w.logits7, W + w.vhat);
+                       net->val_fc1_b, net->val_fc2_w, net->val_fc2_b, W + w.hplanes, W + w.h1, W + w.logits7, W + w.vhat, B,
+                       eps);
     AZ_LAUNCH_CHECK("training forward");
     // ---- loss and its gradients (alphazero/loss.py:29-63)
     if (int rc = az_loss_fwd_bwd(7, W + w.logits7, W + w.vhat, target_p, z, valid, B, out3, W + w.dlogits7, W + w.dv, stream))
@@ -846,62 +961,58 @@ int az_c4_train_fwd_bwd(const az_c4_train_net* net, const float* x, const uint8_
     // ---- backward
     hipLaunchKernelGGL(k_train_head_fc_bwd, dim3(B), dim3(TT), 0, st, x, W + w.dlogits7, W + w.dv, W + w.vhat, W + w.h1,
                        W + w.hplanes, W + w.zh, W + w.stat_h, net->pol_fc_w, net->val_fc1_w, net->val_fc2_w, W + w.dh1,
-                       W + w.dpre2, W + w.dcl, W + w.dyh, part, counter, W + w.sums_h, net->pol_bn.weight_grad,
-                       net->pol_bn.bias_grad, net->val_bn.weight_grad, net->val_bn.bias_grad, B);
+                       W + w.dpre2, W + w.dcl, W + w.dyh, Pout());
+    next();
     {
-        const int nfc = 256 * CELLS + 256 + 256 + 1 + CELLS * 84 + CELLS;
-        hipLaunchKernelGGL(k_train_fc_wgrad, dim3((nfc + TT - 1) / TT), dim3(TT), 0, st, W + w.dh1, W + w.dpre2, W + w.dcl,
+        hipLaunchKernelGGL(k_train_fc_wgrad, dim3(FC_WGRAD_GROUPS), dim3(TT), 0, st, W + w.dh1, W + w.dpre2, W + w.dcl,
                            W + w.h1, W + w.hplanes, B, net->val_fc1_w_grad, net->val_fc1_b_grad, net->val_fc2_w_grad,
                            net->val_fc2_b_grad, net->pol_fc_w_grad, net->pol_fc_b_grad);
     }
     float* g0 = W + w.g0;              // gradient at a block's output batch-norm (dU) / at the stem's
     float* g1 = W + w.g1;              // gradient at a block's first batch-norm
-    float* sums = W + w.sums;
     float* acc0 = W + w.bn_acc, * acc1 = acc0 + 64, * acc2 = acc0 + 128;
-    {
-        const BnBack hb{W + w.stat_h, nullptr, W + w.sums_h};
-        hipLaunchKernelGGL(k_train_head_conv_bwd, dim3(B), dim3(TT), 0, st, W + w.dyh, W + w.zh, hb, net->pol_bn.weight,
-                           net->val_bn.weight, net->pol_conv_w, net->val_conv_w, (const float*)Xk(nb), (const float*)Zl(2 * nb),
-                           (const float*)St(2 * nb), g0, W + w.pwh, part, counter, sums, nb > 0 ? acc2 : acc0, B);
-    }
+    hipLaunchKernelGGL(k_train_head_conv_bwd, dim3(B), dim3(TT), 0, st, W + w.dyh, W + w.zh, W + w.stat_h, Pin(),
+                       net->pol_bn.weight, net->val_bn.weight, net->pol_bn.weight_grad, net->pol_bn.bias_grad,
+                       net->val_bn.weight_grad, net->val_bn.bias_grad, net->pol_conv_w, net->val_conv_w, (const float*)Xk(nb),
+                       (const float*)Zl(2 * nb), (const float*)St(2 * nb), g0, W + w.pwh, Pout(), B);
+    next();
     for (int k = nb - 1; k >= 0; --k) {
         const bool first = k == nb - 1;                 // first application to be differentiated: its share is stored
-        const BnBack ob2{St(2 + 2 * k), net->bn2.weight, sums};
-        const BnRef bn1{St(1 + 2 * k), net->bn1.weight, net->bn1.bias};
+        const BnBack ob2{St(2 + 2 * k), net->bn2.weight};
         // second conv of block k: A = ReLU(BN1(Z1)), previous batch-norm = BN1 over Z1
         if (first)
-            hipLaunchKernelGGL((k_train_conv_bwd<true, false, false>), dim3(B), dim3(TT), BWD_LDS, st, g0, Zl(2 + 2 * k), ob2,
-                               Zl(1 + 2 * k), bn1, (const float*)nullptr, W + w.wb2, (const float*)nullptr, g1, Zl(1 + 2 * k),
-                               St(1 + 2 * k), W + w.pw2, part, counter, sums, acc1, B);
+            hipLaunchKernelGGL((k_train_conv_bwd<true, false, false>), dim3(B), dim3(TTC), BWD_LDS, st, g0, Zl(2 + 2 * k), ob2, Pin(),
+                               acc2, Zl(1 + 2 * k), St(1 + 2 * k), net->bn1.weight, net->bn1.bias, nof, W + w.wb2, nof, g1,
+                               Zl(1 + 2 * k), St(1 + 2 * k), W + w.pw2, Pout(), B);
         else
-            hipLaunchKernelGGL((k_train_conv_bwd<true, false, true>), dim3(B), dim3(TT), BWD_LDS, st, g0, Zl(2 + 2 * k), ob2,
-                               Zl(1 + 2 * k), bn1, (const float*)nullptr, W + w.wb2, (const float*)nullptr, g1, Zl(1 + 2 * k),
-                               St(1 + 2 * k), W + w.pw2, part, counter, sums, acc1, B);
+            hipLaunchKernelGGL((k_train_conv_bwd<true, false, true>), dim3(B), dim3(TTC), BWD_LDS, st, g0, Zl(2 + 2 * k), ob2, Pin(),
+                               acc2, Zl(1 + 2 * k), St(1 + 2 * k), net->bn1.weight, net->bn1.bias, nof, W + w.wb2, nof, g1,
+                               Zl(1 + 2 * k), St(1 + 2 * k), W + w.pw2, Pout(), B);
+        next();
         // first conv of block k: A = X_k (stored), residual gradient g0 added, previous batch-norm = BN2 of block
         // k - 1 over its Z2, or the stem's over Z0
-        const BnBack ob1{St(1 + 2 * k), net->bn1.weight, sums};
-        const BnRef unused{nullptr, nullptr, nullptr};
+        const BnBack ob1{St(1 + 2 * k), net->bn1.weight};
         if (first)
-            hipLaunchKernelGGL((k_train_conv_bwd<false, true, false>), dim3(B), dim3(TT), BWD_LDS, st, g1, Zl(1 + 2 * k), ob1,
-                               (const float*)nullptr, unused, (const float*)Xk(k), W + w.wb1, (const float*)g0, g0, Zl(2 * k),
-                               St(2 * k), W + w.pw1, part, counter, sums, k > 0 ? acc2 : acc0, B);
+            hipLaunchKernelGGL((k_train_conv_bwd<false, true, false>), dim3(B), dim3(TTC), BWD_LDS, st, g1, Zl(1 + 2 * k), ob1, Pin(),
+                               acc1, nof, nof, nof, nof, (const float*)Xk(k), W + w.wb1, (const float*)g0, g0, Zl(2 * k), St(2 * k),
+                               W + w.pw1, Pout(), B);
         else
-            hipLaunchKernelGGL((k_train_conv_bwd<false, true, true>), dim3(B), dim3(TT), BWD_LDS, st, g1, Zl(1 + 2 * k), ob1,
-                               (const float*)nullptr, unused, (const float*)Xk(k), W + w.wb1, (const float*)g0, g0, Zl(2 * k),
-                               St(2 * k), W + w.pw1, part, counter, sums, k > 0 ? acc2 : acc0, B);
+            hipLaunchKernelGGL((k_train_conv_bwd<false, true, true>), dim3(B), dim3(TTC), BWD_LDS, st, g1, Zl(1 + 2 * k), ob1, Pin(),
+                               acc1, nof, nof, nof, nof, (const float*)Xk(k), W + w.wb1, (const float*)g0, g0, Zl(2 * k), St(2 * k),
+                               W + w.pw1, Pout(), B);
+        next();
     }
     {
-        const BnBack ob0{St(0), net->stem_bn.weight, sums};
-        hipLaunchKernelGGL(k_train_stem_bwd, dim3(B), dim3(TT), 0, st, x, g0, Zl(0), ob0, W + w.pws, B);
+        const BnBack ob0{St(0), net->stem_bn.weight};
+        hipLaunchKernelGGL(k_train_stem_bwd, dim3(B), dim3(TT), 0, st, x, g0, Zl(0), ob0, Pin(), acc0, W + w.pws, B);
     }
     {
-        const int nfin = 2 * 9 * TC * TC + 18 * TC + 128 + TC;
         const RunStat r0{net->stem_bn.running_mean, net->stem_bn.running_var, (long long*)net->stem_bn.num_batches_tracked};
         const RunStat r1{net->bn1.running_mean, net->bn1.running_var, (long long*)net->bn1.num_batches_tracked};
         const RunStat r2{net->bn2.running_mean, net->bn2.running_var, (long long*)net->bn2.num_batches_tracked};
         const RunStat rp{net->pol_bn.running_mean, net->pol_bn.running_var, (long long*)net->pol_bn.num_batches_tracked};
         const RunStat rv{net->val_bn.running_mean, net->val_bn.running_var, (long long*)net->val_bn.num_batches_tracked};
-        hipLaunchKernelGGL(k_train_finish, dim3((nfin + TT - 1) / TT), dim3(TT), 0, st, W + w.pw1, W + w.pw2, W + w.pws, W + w.pwh,
+        hipLaunchKernelGGL(k_train_finish, dim3(FINISH_GROUPS), dim3(TT), 0, st, W + w.pw1, W + w.pw2, W + w.pws, W + w.pwh,
                            B, nb, net->c1_w_grad, net->c2_w_grad, net->stem_w_grad, net->pol_conv_w_grad, net->pol_conv_b_grad,
                            net->val_conv_w_grad, W + w.bn_acc, net->stem_bn.weight_grad, net->stem_bn.bias_grad,
                            net->bn1.weight_grad, net->bn1.bias_grad, net->bn2.weight_grad, net->bn2.bias_grad, stats,

@@ -257,7 +257,8 @@ class DeviceReplayWindow:
     are turned into examples by the az_examples_from_records kernel: the same x, p, z, p_valid and
     model_version that ReplayBufferDataset.__getitem__ returns, without a per-state Python call.
     `sample(batch_size)` draws like ReplayBufferSampler (uniform over the window, with replacement
-    only when the batch is larger than the window) but from torch's device RNG."""
+    only when the batch is larger than the window): from torch's device RNG, or -- given a seed and a draw
+    counter in device memory -- in one launch of az_sample_window, which a recorded training step can replay."""
 
     def __init__(self, game_cls, capacity=64 * 1024, device='cuda'):
         import ctypes as C
@@ -279,6 +280,7 @@ class DeviceReplayWindow:
         self.p_valid = torch.zeros(self.capacity, self.A, dtype=torch.bool, device=self.device)
         self.model_version = torch.zeros(self.capacity, dtype=torch.int32, device=self.device)
         self.count = 0                                           # states ever added
+        self.count_dev = torch.zeros(1, dtype=torch.int64, device=self.device)    # the same, where kernels read it
         self.num_games = 0
 
     def __len__(self):
@@ -324,6 +326,7 @@ class DeviceReplayWindow:
         self.p_valid.index_copy_(0, dst, valid[src].bool())
         self.model_version.index_copy_(0, dst, version[src])
         self.count += total
+        self.count_dev.fill_(self.count)
         self.num_games += n
         return total
 
@@ -344,15 +347,42 @@ class DeviceReplayWindow:
             idx = torch.randperm(n, device=self.device, generator=generator)[:batch_size]
         return (idx + (self.count - n)) % self.capacity
 
-    def sample(self, batch_size, generator=None):
+    def sample(self, batch_size, generator=None, seed=None, draw_dev=None):
+        if seed is not None:
+            torch = self._torch
+            x = torch.empty((batch_size,) + self.shape, dtype=torch.float32, device=self.device)
+            p = torch.empty(batch_size, self.A, dtype=torch.float32, device=self.device)
+            z = torch.empty(batch_size, 1, dtype=torch.float32, device=self.device)
+            valid = torch.empty(batch_size, self.A, dtype=torch.bool, device=self.device)
+            self.sample_into(x, p, z, valid, seed=seed, draw_dev=draw_dev)
+            return {'x': x, 'p': p, 'z': z, 'p_valid': valid}
         idx = self._sample_index(batch_size, generator)
         return {'x': self.x[idx], 'p': self.p[idx], 'z': self.z[idx], 'p_valid': self.p_valid[idx],
                 'model_version': self.model_version[idx]}
 
-    def sample_into(self, x, p, z, p_valid, generator=None):
-        """The same draw as sample(len(x)), gathered into the caller's tensors (a training step recorded as a
-        HIP graph reads its batch from fixed addresses)."""
+    def kernel_sampling(self, batch_size):
+        """True when az_sample_window can draw this batch from this window (its limits: 262144 states, 2048 per batch)."""
+        return self.capacity <= (1 << 18) and 0 < batch_size <= 2048
+
+    def sample_into(self, x, p, z, p_valid, generator=None, seed=None, draw_dev=None):
+        """The same kind of draw as sample(len(x)), gathered into the caller's tensors (a training step recorded as
+        a HIP graph reads its batch from fixed addresses).  With `seed` and `draw_dev` (int64 device tensor [1]) the
+        draw and the gather are ONE launch (az_sample_window) that is a function of (seed, draw_dev[0]) and increments
+        draw_dev[0]: recorded in a graph, every replay takes a new batch from the window as it then is."""
         torch = self._torch
+        if seed is not None:
+            C, ptr = self._C, self._lib.ptr
+            assert draw_dev is not None and draw_dev.dtype == torch.int64 and draw_dev.device.type == self.device.type
+            assert x.is_contiguous() and p.is_contiguous() and z.is_contiguous() and p_valid.is_contiguous()
+            if len(self) == 0:
+                raise StopIteration
+            with torch.cuda.device(self.device):
+                st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+                self._lib.check(self.lib.az_sample_window(
+                    ptr(self.x), ptr(self.p), ptr(self.z), ptr(self.p_valid), int(np.prod(self.shape)), self.A,
+                    ptr(self.count_dev), self.capacity, C.c_uint64(int(seed) & (2 ** 64 - 1)), ptr(draw_dev), x.shape[0],
+                    ptr(x), ptr(p), ptr(z), ptr(p_valid), st))
+            return
         idx = self._sample_index(x.shape[0], generator)
         torch.index_select(self.x, 0, idx, out=x)
         torch.index_select(self.p, 0, idx, out=p)

@@ -1,11 +1,13 @@
 """TrainingWorker with the reference's constructor and process_batch() contract
 (alphazero/training.py:15-125): SGD + momentum + weight decay, MultiStepLR, masked
 cross-entropy + MSE, weights published after every step.  On the GPU the loss with its gradients and the
-optimiser update are hand-written kernels (loss.AlphaZeroLoss, optim.FlatSGD; csrc/az_train.hip); the network's
-forward and backward in between are PyTorch's.  With a DeviceReplayWindow on the GPU the whole step (forward,
-loss, backward, update: about 300 small launches) is recorded once as a HIP graph after three ordinary steps and
-replayed from then on, the batch gathered into fixed tensors and the learning rate read from device memory
-(AZ_TRAIN_GRAPH=0 or record_step=False keeps every step eager).  The summary
+optimiser update are hand-written kernels (loss.AlphaZeroLoss, optim.FlatSGD; csrc/az_train.hip).  For the
+Connect Four network with 32 trunk channels the whole pass -- forward on the batch's statistics, loss, backward,
+running statistics -- is hand-written too (train_c4.C4TrainStep, csrc/az_train_c4.hip: 35 launches for six blocks,
+no vendor convolution, no autograd; AZ_TRAIN_HANDWRITTEN=0 switches it off); other networks go through PyTorch's
+forward and backward.  With a DeviceReplayWindow on the GPU the whole step is recorded once as a HIP graph after
+three ordinary steps and replayed from then on, the batch gathered into fixed tensors and the learning rate read
+from device memory (AZ_TRAIN_GRAPH=0 or record_step=False keeps every step eager).  The summary
 writer and model server are duck-typed (`add_scalar`, `update(model, version)`).  `dataset` is a
 ReplayBufferDataset (the reference's per-state sample dicts) or a DeviceReplayWindow (batches taken
 straight from tensors on the GPU)."""
@@ -51,6 +53,21 @@ class TrainingWorker:
         self._record = bool(record_step and torch.device(device).type == 'cuda' and hasattr(dataset, 'sample_into')
                             and grad_sync is None and hasattr(self._optimizer, 'step_recorded'))
         self._graph = None
+        # batches from a DeviceReplayWindow are drawn and gathered by one kernel (az_sample_window): a function of a
+        # seed taken from torch's generator here and of a draw counter in device memory, so a recorded step can
+        # contain its own sampling
+        self._draw = None
+        if (torch.device(device).type == 'cuda' and hasattr(dataset, 'kernel_sampling')
+                and dataset.kernel_sampling(self._batch_size)):
+            self._sample_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            self._draw = torch.zeros(1, dtype=torch.int64, device=device)
+        # the hand-written pass binds the parameters and their .grad tensors where FlatSGD has put them
+        self._hand = None
+        if torch.device(device).type == 'cuda' and os.environ.get('AZ_TRAIN_HANDWRITTEN', '1') != '0' and self._batch_size >= 2:
+            from . import train_c4
+            from .loss import AlphaZeroLoss
+            if train_c4.supports(self._model) and type(self._loss) is AlphaZeroLoss:
+                self._hand = train_c4.C4TrainStep(self._model)
 
     @property
     def model(self):
@@ -59,7 +76,10 @@ class TrainingWorker:
     def _batch(self):
         if hasattr(self._dataset, 'sample'):
             # DeviceReplayWindow: the window already lives on the GPU as tensors
-            b = self._dataset.sample(self._batch_size)
+            if self._draw is not None:
+                b = self._dataset.sample(self._batch_size, seed=self._sample_seed, draw_dev=self._draw)
+            else:
+                b = self._dataset.sample(self._batch_size)
             return (b['x'].to(self._device), b['p'].to(self._device), b['z'].to(self._device),
                     b['p_valid'].to(self._device), None)
         items = [self._dataset[i] for i in next(self._sampler)]
@@ -101,11 +121,19 @@ class TrainingWorker:
         if self._record and self._iter >= self.EAGER_STEPS:
             return self._process_batch_recorded()
         x, p, z, p_valid, extra = self._batch()
-        p_hat, v_hat = self._model(x, p_valid)
-        policy_loss, value_loss = self._loss(p, z, p_hat, v_hat, p_valid)
-        self._optimizer.zero_grad()
-        total = policy_loss + value_loss
-        total.backward()
+        if self._hand is not None:
+            # forward, loss and backward in the hand-written kernels: the gradients land in the .grad tensors
+            out3 = self._hand.run(x.contiguous(), p.contiguous(), z.contiguous(), p_valid.contiguous())
+            policy_loss, value_loss = out3[0], out3[1]
+            assert float(out3[2]) < 1e-6, f'Target policy must be a valid distribution: {p}'       # loss.py:58-59
+            total = policy_loss + value_loss
+            p_hat, v_hat = self._hand.logits, self._hand.v_hat.reshape(-1, 1)
+        else:
+            p_hat, v_hat = self._model(x, p_valid)
+            policy_loss, value_loss = self._loss(p, z, p_hat, v_hat, p_valid)
+            self._optimizer.zero_grad()
+            total = policy_loss + value_loss
+            total.backward()
         if self._grad_sync is not None:
             self._grad_sync(self._model)
         self._optimizer.step()
@@ -134,27 +162,38 @@ class TrainingWorker:
         self._gp = torch.empty((B,) + tuple(ds.p.shape[1:]), dtype=ds.p.dtype, device=dev)
         self._gz = torch.empty((B,) + tuple(ds.z.shape[1:]), dtype=ds.z.dtype, device=dev)
         self._gvalid = torch.empty((B,) + tuple(ds.p_valid.shape[1:]), dtype=ds.p_valid.dtype, device=dev)
-        ds.sample_into(self._gx, self._gp, self._gz, self._gvalid)
+        in_graph = self._draw is not None
+        if not in_graph:
+            ds.sample_into(self._gx, self._gp, self._gz, self._gvalid)
+        self._sample_in_graph = in_graph
         self._optimizer.set_recorded_lr()
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            p_hat, v_hat = self._model(self._gx, self._gvalid)
-            policy_loss, value_loss = self._loss(self._gp, self._gz, p_hat, v_hat, self._gvalid)
-            self._optimizer.zero_grad()
-            total = policy_loss + value_loss
-            total.backward()
+            if in_graph:
+                ds.sample_into(self._gx, self._gp, self._gz, self._gvalid, seed=self._sample_seed, draw_dev=self._draw)
+            if self._hand is not None:
+                out3 = self._hand.run(self._gx, self._gp, self._gz, self._gvalid)
+                policy_loss, value_loss, guard = out3[0], out3[1], out3[2:3]
+                total = policy_loss + value_loss
+            else:
+                p_hat, v_hat = self._model(self._gx, self._gvalid)
+                policy_loss, value_loss = self._loss(self._gp, self._gz, p_hat, v_hat, self._gvalid)
+                self._optimizer.zero_grad()
+                total = policy_loss + value_loss
+                total.backward()
+                guard = getattr(self._loss, 'target_deviation', None)
             # the update itself is conditional on the loss kernel's check of the targets, on the device: a batch
             # that fails it changes no weight (the reference asserts before optimizer.step(), loss.py:58-59)
-            self._optimizer.step_recorded(guard=getattr(self._loss, 'target_deviation', None))
+            self._optimizer.step_recorded(guard=guard)
         self._graph = graph
         self._g_out = (policy_loss.detach(), value_loss.detach(), total.detach())
         return graph
 
     def _process_batch_recorded(self):
         if self._graph is None:
-            self._record_step()                       # (its batch is already in place)
-        else:
+            self._record_step()                       # (without in-graph sampling its batch is already in place)
+        elif not self._sample_in_graph:
             self._dataset.sample_into(self._gx, self._gp, self._gz, self._gvalid)
         self._optimizer.set_recorded_lr()
         self._graph.replay()

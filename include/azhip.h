@@ -243,6 +243,17 @@ int  az_masked_softmax(int32_t game, const float* logits, const int32_t* leaf_in
 int  az_ucb_score(az_engine* e, const uint32_t* N, const float* W, const float* P,
                   const int32_t* num_edges, int32_t n, double* score, int32_t* argmax, void* stream);
 
+/* A training batch from a replay window kept on the device as a ring of `capacity` states (tensors wx
+ * [capacity][x_floats], wp [capacity][num_actions], wz [capacity], wvalid uint8 [capacity][num_actions]; count_dev =
+ * DEVICE int64 {states ever added}): `batch` states drawn uniformly from the last min(count, capacity), without
+ * replacement while batch fits, with replacement otherwise -- ReplayBufferSampler, alphazero/replay_buffer.py:175-195
+ * -- and gathered into x / p / z / valid.  The draw is a function of (seed, draw_dev[0]); the launch increments
+ * draw_dev[0] (DEVICE int64), so a recorded launch draws a new batch at every replay.  capacity <= 262144,
+ * batch <= 2048.  One launch, no host synchronisation.                                                           */
+int  az_sample_window(const float* wx, const float* wp, const float* wz, const uint8_t* wvalid, int32_t x_floats,
+                      int32_t num_actions, const int64_t* count_dev, int32_t capacity, uint64_t seed, int64_t* draw_dev,
+                      int32_t batch, float* x, float* p, float* z, uint8_t* valid, void* stream);
+
 /* ---- training step of the Connect Four network, hand-written forward and backward ---------------------------
  * Replaces, for AlphaZeroC4 with 32 trunk channels in training mode, the forward, loss and backward of
  * alphazero/training.py:57-71 (model(x, p_valid), AlphaZeroLoss, total.backward(): alphazero/models.py:6-87,
