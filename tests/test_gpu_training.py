@@ -425,3 +425,54 @@ def test_window_sampling_kernel():
     h = hits[700:]
     assert h.min().item() > 55 and h.max().item() < 145 and abs(h.std().item() - 8.7) < 1.5, (h.min(), h.max(), h.std())
 
+
+
+def test_hand_written_training_steps_match_the_reference_scalars():
+    """training_c4.json: three process_batch() calls of the REFERENCE's TrainingWorker on the CPU with
+    AlphaZeroC4(2, 32) on four recorded Connect Four games.  The same seeds, games and configuration here with the
+    hand-written pass (csrc/az_train_c4.hip), the HIP loss kernel and FlatSGD on the GPU: every logged scalar within
+    1e-5 relative, the final weights and running statistics within 1e-4, the batch-norm counters equal."""
+    from test_host_cpu import _golden_game
+    from alphazero_amd.config import AlphaZeroConfig
+    from alphazero_amd.replay_buffer import ReplayBufferDataset
+    from alphazero_amd.training import TrainingWorker
+    t = load_json('training_c4.json')
+    cfg = AlphaZeroConfig(conf=t['conf'])
+    ds = ReplayBufferDataset(cfg)
+    for g in t['games']:
+        ds.add_game(_golden_game(cfg, g), 1)
+
+    class Server:
+        def __init__(self):
+            self.versions = []
+
+        def update(self, model, version):
+            self.versions.append(int(version))
+
+    class Writer:
+        def __init__(self):
+            self.rows = []
+
+        def add_scalar(self, tag, value, step):
+            self.rows.append([tag, float(value), int(step)])
+
+    torch.manual_seed(t['model_seed'])
+    np.random.seed(t['sampler_seed'])
+    server, writer = Server(), Writer()
+    tw = TrainingWorker(cfg, server, ds, writer, 'cuda', 0)
+    assert tw._hand is not None
+    assert [tw.process_batch() for _ in range(3)] == t['returns'] and server.versions == t['versions']
+    assert [(r[0], r[2]) for r in writer.rows] == [(r[0], r[2]) for r in t['scalars']]
+    worst = 0.0
+    for got, want in zip(writer.rows, t['scalars']):
+        err = abs(got[1] - want[1]) / max(1.0, abs(want[1]))
+        worst = max(worst, err)
+        assert err <= 1e-5, (got, want)
+    state = tw.model.state_dict()
+    for k, h in t['final'].items():
+        a, b = state[k].detach().cpu().numpy().reshape(-1), unhex(h, '<f4')
+        assert np.allclose(a, b, rtol=1e-4, atol=1e-5), (k, np.abs(a - b).max())
+    for k, v in t['counters'].items():
+        assert int(state[k]) == v, k
+    print('worst relative scalar error vs the reference:', worst)
+

@@ -385,6 +385,51 @@ def test_training_steps_match_the_reference_on_cpu():
     assert exact == len(t['final'])         # in fact bit-identical on this torch build
 
 
+def test_connect_four_training_steps_match_the_reference_on_cpu():
+    # training_c4.json: three process_batch() calls of the reference's TrainingWorker (alphazero/training.py:42-125)
+    # with AlphaZeroC4(2, 32) on four recorded Connect Four games; the same seeds here, on the CPU (PyTorch's
+    # forward and backward, as in the reference)
+    from alphazero_amd.config import AlphaZeroConfig
+    from alphazero_amd.replay_buffer import ReplayBufferDataset
+    from alphazero_amd.training import TrainingWorker
+    t = load_json('training_c4.json')
+    cfg = AlphaZeroConfig(conf=t['conf'])
+    ds = ReplayBufferDataset(cfg)
+    for g in t['games']:
+        ds.add_game(_golden_game(cfg, g), 1)
+
+    class Server:
+        def __init__(self):
+            self.versions = []
+
+        def update(self, model, version):
+            self.versions.append(int(version))
+
+    class Writer:
+        def __init__(self):
+            self.rows = []
+
+        def add_scalar(self, tag, value, step):
+            self.rows.append([tag, float(value), int(step)])
+
+    torch.manual_seed(t['model_seed'])
+    np.random.seed(t['sampler_seed'])
+    server, writer = Server(), Writer()
+    tw = TrainingWorker(cfg, server, ds, writer, 'cpu', 0)
+    state = tw.model.state_dict()
+    for k, h in t['init'].items():
+        assert np.array_equal(state[k].detach().numpy().reshape(-1), unhex(h, '<f4')), k     # same initialisation
+    assert [tw.process_batch() for _ in range(3)] == t['returns'] and server.versions == t['versions']
+    assert [(r[0], r[2]) for r in writer.rows] == [(r[0], r[2]) for r in t['scalars']]
+    for got, want in zip(writer.rows, t['scalars']):
+        assert abs(got[1] - want[1]) <= 1e-6 * max(1.0, abs(want[1])), (got, want)
+    state = tw.model.state_dict()
+    for k, h in t['final'].items():
+        assert np.allclose(state[k].detach().numpy().reshape(-1), unhex(h, '<f4'), rtol=1e-5, atol=1e-6), k
+    for k, v in t['counters'].items():
+        assert int(state[k]) == v, k
+
+
 def test_tictactoe_solver_known_line():
     # the positions of alphazero/test/test_games.py:69-92, answers as the reference's solver gave them
     from alphazero_amd.games.tictactoe import TicTacToe
