@@ -847,8 +847,10 @@ def main():
                 dt = (time.perf_counter() - t1) / loop_steps
                 return {
                     'training_step_ms': train_ms, 'batch_size': 128, 'samples_per_s': 128 / (train_ms * 1e-3),
-                    'step': 'sample from the device window + forward + az_loss_fwd_bwd + backward + az_sgd_momentum + publish; '
-                            'forward .. update replayed as one recorded HIP graph',
+                    'step': 'az_sample_window + az_c4_train_fwd_bwd (hand-written forward on batch statistics, loss, backward: '
+                            f'{4 * blocks + 11} launches, no vendor convolution, no autograd) + az_sgd_momentum + publish; replayed as '
+                            'one recorded HIP graph',
+                    'hand_written_pass': tw._hand is not None,
                     'selfplay_with_training': {'value': G / dt, 'unit': 'positions/s', 'ms_per_step': 1e3 * dt,
                                                'steps': loop_steps,
                                                'per_step': 'one move of every game (records stay on the device) + one SGD step + '
