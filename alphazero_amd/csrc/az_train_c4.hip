@@ -14,7 +14,8 @@
 //   * activations: channel-last fp32 [board][cell][32]; kept per layer: the raw conv outputs Z (batch-norm input)
 //     and the block inputs X; everything else (ReLU(BN(Z)), x-hat, ReLU masks) is recomputed from those while a
 //     tile is staged into LDS;
-//   * forward conv: thread = (output channel, 6 of the board's cells), input tile and the conv's weights in LDS;
+//   * forward conv: the board's 42 x 32 x 288 contraction on v_mfma_f32_32x32x2_f32, input tile and weights in LDS,
+//     eight waves = two cell tiles x four tap groups;
 //   * backward of a conv layer in ONE launch: dZ from the incoming gradient by the batch-norm backward formula
 //     (while staging), input gradient (the conv with flipped taps and transposed weights), ReLU mask, the partial
 //     sums of the previous batch-norm's backward, and the board's share of the weight gradient (summed over the
@@ -36,8 +37,14 @@
 #define NPOS 6                 // cells per thread there (8 groups x 6 >= 42)
 #define TTC 512                // threads per workgroup of the 3x3 conv kernels: two waves per SIMD, 16 cell groups
 #define NPC 3                  // cells per thread there (16 groups x 3 >= 42): cell = group + 16 k
+#define TS 33                  // floats per cell in the conv kernels' LDS tiles (32 channels + 1: lanes that read one
+                               // channel of 32 cells hit different banks)
+#define PBS 65                 // floats per channel row of the partial-result buffer of the conv kernels
 #define EPT 3                  // elements of a board tensor [42][32] per thread of a conv kernel: element tid + 512 j is
                                // (cell = group + 16 j, channel = tid & 31) -- the same cells the thread computes
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 __device__ __forceinline__ int pad_index(int cell) { return (cell / 7 + 1) * 9 + cell % 7 + 1; }
 __device__ __forceinline__ int tap_offset(int tap) { return (tap / 3 - 1) * 9 + tap % 3 - 1; }
@@ -183,33 +190,68 @@ __device__ __forceinline__ void stage_activation(float* tile, const float* zin, 
     }
 }
 
-// acc[k] = sum over taps and input channels of tile[cell_k + SIGN * tap offset][ci] * w[tap][ci][out]: the forward
-// conv (SIGN = +1, w = [tap][ci][co], out = co) and the input gradient (SIGN = -1, w = [tap][co][ci], out = ci)
+// The 3x3 conv of one board on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32: D[32 out][32 cells] += W[out][2 k]
+// X[2 k][cells]), by the workgroup's eight waves: wave = (cell tile: cells 0..31 / 32..63 of which 42 exist, tap
+// group: taps 0-2 / 3-4 / 5-6 / 7-8).  The forward conv (SIGN = +1, w = [tap][ci][co]) and the input gradient
+// (SIGN = -1, w = [tap][co][ci]) are the same loop.  A wave leaves its partial result in pbuf [tap group][out][PBS];
+// the caller adds the four groups up in order.  tile = [72 padded cells][TS].
 template <int SIGN>
-__device__ __forceinline__ void conv_cells(const float* tile, const float* w, int out, int g, float (&acc)[NPC]) {
-    int pi[NPC];
+__device__ __forceinline__ void conv_mfma(const float* tile, const float* w, float* pbuf, int wave, int lane) {
+    const int col = lane & 31, h = lane >> 5, pt = wave & 1, kq = wave >> 1;
+    const int cell = pt * 32 + col;
+    const int pi = pad_index(cell < CELLS ? cell : 0);
+    const int t0 = kq == 0 ? 0 : 1 + 2 * kq, nt = kq == 0 ? 3 : 2;
+    f32x16 acc;
 #pragma unroll
-    for (int k = 0; k < NPC; ++k) {
-        const int cell = g + 16 * k;
-        pi[k] = pad_index(cell < CELLS ? cell : 0);
-        acc[k] = 0.0f;
-    }
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {
-        const int off = SIGN * tap_offset(tap);
-        const float* wt = w + tap * TC * TC + out;
-#pragma unroll 4
-        for (int c4 = 0; c4 < TC / 4; ++c4) {
-            const float w0 = wt[(4 * c4) * TC], w1 = wt[(4 * c4 + 1) * TC], w2 = wt[(4 * c4 + 2) * TC], w3 = wt[(4 * c4 + 3) * TC];
+    for (int t = t0; t < t0 + nt; ++t) {
+        const float* xs = tile + (pi + SIGN * tap_offset(t)) * TS + h;
+        const float* ws = w + (t * TC + h) * TC + col;
 #pragma unroll
-            for (int k = 0; k < NPC; ++k) {
-                const float4 a = *reinterpret_cast<const float4*>(tile + (pi[k] + off) * TC + 4 * c4);
-                acc[k] = fmaf(a.x, w0, acc[k]);
-                acc[k] = fmaf(a.y, w1, acc[k]);
-                acc[k] = fmaf(a.z, w2, acc[k]);
-                acc[k] = fmaf(a.w, w3, acc[k]);
-            }
+        for (int s2 = 0; s2 < 16; ++s2) acc = MFMA32(ws[2 * s2 * TC], xs[2 * s2], acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pbuf[(kq * TC + (r & 3) + 8 * (r >> 2) + 4 * h) * PBS + cell] = acc[r];
+}
+// the four tap groups' partial results of (channel c, cell), added in order
+__device__ __forceinline__ float conv_total(const float* pbuf, int c, int cell) {
+    const float* p = pbuf + c * PBS + cell;
+    return ((p[0] + p[TC * PBS]) + p[2 * TC * PBS]) + p[3 * TC * PBS];
+}
+
+// The board's share of a conv's weight gradient on the same instruction: dW[tap][ci][co] = sum over cells of
+// A[cell + tap][ci] dZ[cell][co] = D[32 ci][32 co] with the cells as k, 21 steps of two; wave w takes tap w (wave 0
+// also the ninth).  out = [tap][ci][co].
+// What earlier applications of the shared block have left in this wave's part of the board's share (requested at
+// the start of the launch, used at its end).
+struct WgOld { f32x16 a, b; };
+template <bool ACCUM>
+__device__ __forceinline__ WgOld wgrad_load_old(const float* out, int wave, int lane) {
+    WgOld o;
+    const int col = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        o.a[r] = ACCUM ? out[(wave * TC + row) * TC + col] : 0.0f;
+        o.b[r] = (ACCUM && wave == 0) ? out[(8 * TC + row) * TC + col] : 0.0f;
+    }
+    return o;
+}
+template <bool ACCUM>
+__device__ __forceinline__ void wgrad_mfma(const float* at, const float* dzt, float* out, const WgOld& old, int wave, int lane) {
+    const int col = lane & 31, h = lane >> 5;
+#pragma unroll 1
+    for (int t = wave; t < 9; t += 8) {
+        const int off = tap_offset(t);
+        f32x16 acc = t == wave ? old.a : old.b;
+#pragma unroll 3
+        for (int s2 = 0; s2 < CELLS / 2; ++s2) {
+            const int pi = pad_index(2 * s2 + h);
+            acc = MFMA32(at[(pi + off) * TS + col], dzt[pi * TS + col], acc);
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[(t * TC + (r & 3) + 8 * (r >> 2) + 4 * h) * TC + col] = acc[r];
     }
 }
 
@@ -242,10 +284,11 @@ k_train_conv_fwd(const float* __restrict__ zin, const float* __restrict__ part_i
                  int boards, float eps) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wl = lds;                                   // [9][32][32]
-    float* tile = lds + 9 * TC * TC;                   // [72][32]
-    float* sc = tile + PADCELLS * TC;                  // [32], [32]
+    float* tile = lds + 9 * TC * TC;                   // [72][TS]
+    float* sc = tile + PADCELLS * TS;                  // [32], [32]
     float* sh = sc + TC;
     float* red = sh + TC;                              // [1024]
+    float* pbuf = red + 1024;                          // [4][32][PBS]
     __shared__ double tot[64], scratch[512];
     __shared__ float st[96];
     const int b = blockIdx.x, tid = threadIdx.x, co = tid & 31, g = tid >> 5;
@@ -258,7 +301,7 @@ k_train_conv_fwd(const float* __restrict__ zin, const float* __restrict__ part_i
         xr[j] = (RES && i < CELLS * TC) ? xprev[base + i] : 0.0f;
     }
     const WRegs wr = load_conv_weights(wf);
-    for (int i = tid; i < PADCELLS * TC; i += TTC) tile[i] = 0.0f;
+    for (int i = tid; i < PADCELLS * TS; i += TTC) tile[i] = 0.0f;
     reduce_partials(part_in, boards, tot, scratch);
     store_conv_weights(wl, wr);
     stats_from_totals(tot, TC, (long)boards * CELLS, eps, st, bn.stat_keep);
@@ -272,19 +315,20 @@ k_train_conv_fwd(const float* __restrict__ zin, const float* __restrict__ part_i
             if (RES) a += xr[j];
             a = fmaxf(a, 0.0f);
             if (WRITE_X) xout[base + i] = a;
-            tile[pad_index(i >> 5) * TC + co] = a;
+            tile[pad_index(i >> 5) * TS + co] = a;
         }
     }
     __syncthreads();
-    float acc[NPC];
-    conv_cells<1>(tile, wl, co, g, acc);
+    conv_mfma<1>(tile, wl, pbuf, tid >> 6, tid & 63);
+    __syncthreads();
     float s = 0.0f, q = 0.0f;
 #pragma unroll
     for (int k = 0; k < NPC; ++k) {
         const int cell = g + 16 * k;
         if (cell < CELLS) {
-            zout[base + cell * TC + co] = acc[k];
-            s += acc[k]; q = fmaf(acc[k], acc[k], q);
+            const float zv = conv_total(pbuf, co, cell);
+            zout[base + cell * TC + co] = zv;
+            s += zv; q = fmaf(zv, zv, q);
         }
     }
     board_partials(s, q, red, part_out + (size_t)b * 64);
@@ -626,9 +670,9 @@ k_train_conv_bwd(const float* __restrict__ dyout, const float* __restrict__ zout
                  float* __restrict__ part_out, int boards) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wl = lds;                                   // [9][32 co][32 ci]
-    float* dzt = lds + 9 * TC * TC;                    // [72][32] dZ
-    float* at = dzt + PADCELLS * TC;                   // [72][32] A
-    float* sc = at + PADCELLS * TC;                    // 7 x [32]
+    float* dzt = lds + 9 * TC * TC;                    // [72][TS] dZ
+    float* at = dzt + PADCELLS * TS;                   // [72][TS] A
+    float* sc = at + PADCELLS * TS;                    // 7 x [32]
     float* sh = sc + TC;
     float* k1 = sh + TC;
     float* m1 = k1 + TC;
@@ -636,12 +680,13 @@ k_train_conv_bwd(const float* __restrict__ dyout, const float* __restrict__ zout
     float* mean = m2 + TC;
     float* invstd = mean + TC;
     float* red = invstd + TC;                          // [1024]
+    float* pbuf = red + 1024;                          // [4][32][PBS]
     __shared__ double tot[64], scratch[512];
     const int b = blockIdx.x, tid = threadIdx.x, lane32 = tid & 31, g = tid >> 5;
     const float inv_n = 1.0f / (float)((long)boards * CELLS);
     const size_t base = (size_t)b * CELLS * TC;
     // every global load of the launch, before the first wait (element tid + 512 j = (cell g + 16 j, channel lane32):
-    // the cells this thread also computes the input gradient of)
+    // the cells this thread also finishes the input gradient of)
     float dyr[EPT], zor[EPT], ar[EPT], rr[EPT], zpr[EPT];
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
@@ -654,8 +699,9 @@ k_train_conv_bwd(const float* __restrict__ dyout, const float* __restrict__ zout
         zpr[j] = in ? (MODE_T ? ar[j] : zprev[base + i]) : 0.0f;       // MODE_T: the previous batch-norm's input is zin
     }
     const WRegs wr = load_conv_weights(wb);
+    const WgOld wold = wgrad_load_old<ACCUM>(pw + (size_t)b * 9 * TC * TC, tid >> 6, tid & 63);
     const float sp_mean = stat_prev[lane32], sp_inv = stat_prev[32 + lane32];
-    for (int i = tid; i < 2 * PADCELLS * TC; i += TTC) dzt[i] = 0.0f;         // both tiles
+    for (int i = tid; i < 2 * PADCELLS * TS; i += TTC) dzt[i] = 0.0f;         // both tiles
     reduce_partials(part_in, boards, tot, scratch);
     store_conv_weights(wl, wr);
     bn_back_coeff(ob, tot, TC, inv_n, k1, m1, m2, mean, invstd);
@@ -670,47 +716,23 @@ k_train_conv_bwd(const float* __restrict__ dyout, const float* __restrict__ zout
         if (i < CELLS * TC) {
             const int pi = pad_index(i >> 5);
             const float xh = (zor[j] - mean[lane32]) * invstd[lane32];
-            dzt[pi * TC + lane32] = k1[lane32] * (dyr[j] - m1[lane32] - xh * m2[lane32]);
+            dzt[pi * TS + lane32] = k1[lane32] * (dyr[j] - m1[lane32] - xh * m2[lane32]);
             a_own[j] = MODE_T ? fmaxf(fmaf(ar[j], sc[lane32], sh[lane32]), 0.0f) : ar[j];
-            at[pi * TC + lane32] = a_own[j];
+            at[pi * TS + lane32] = a_own[j];
         }
     }
     __syncthreads();
-    // ---- the board's share of the weight gradient: thread (co, two input channels), nine taps
-    {
-        const int co = lane32, cg = g;
-        float acc[9][2];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) { acc[t][0] = 0.0f; acc[t][1] = 0.0f; }
-#pragma unroll 2
-        for (int cell = 0; cell < CELLS; ++cell) {
-            const int pi = pad_index(cell);
-            const float d = dzt[pi * TC + co];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const float2 a = *reinterpret_cast<const float2*>(at + (pi + tap_offset(t)) * TC + 2 * cg);
-                acc[t][0] = fmaf(a.x, d, acc[t][0]);
-                acc[t][1] = fmaf(a.y, d, acc[t][1]);
-            }
-        }
-        float* out = pw + (size_t)b * 9 * TC * TC;
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int idx = (t * TC + 2 * cg + j) * TC + co;
-                out[idx] = ACCUM ? out[idx] + acc[t][j] : acc[t][j];
-            }
-    }
-    // ---- input gradient, mask, the previous batch-norm's sums: thread (ci, three cells)
-    float acc[NPC];
-    conv_cells<-1>(dzt, wl, lane32, g, acc);
+    // ---- input gradient (into pbuf) and the board's share of the weight gradient, both on the matrix cores
+    conv_mfma<-1>(dzt, wl, pbuf, tid >> 6, tid & 63);
+    wgrad_mfma<ACCUM>(at, dzt, pw + (size_t)b * 9 * TC * TC, wold, tid >> 6, tid & 63);
+    __syncthreads();
+    // ---- mask, the previous batch-norm's sums: thread (ci, three cells)
     float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
     for (int k = 0; k < NPC; ++k) {
         const int cell = g + 16 * k;
         if (cell < CELLS) {
-            float d = acc[k];
+            float d = conv_total(pbuf, lane32, cell);
             if (RES) d += rr[k];
             if (!(a_own[k] > 0.0f)) d = 0.0f;
             dyprev[base + cell * TC + lane32] = d;
@@ -872,8 +894,8 @@ Ws layout(int boards, int blocks) {
     w.total = o;
     return w;
 }
-constexpr int FWD_LDS = (9 * TC * TC + PADCELLS * TC + 2 * TC + 1024) * 4;
-constexpr int BWD_LDS = (9 * TC * TC + 2 * PADCELLS * TC + 7 * TC + 1024) * 4;
+constexpr int FWD_LDS = (9 * TC * TC + PADCELLS * TS + 2 * TC + 1024 + 4 * TC * PBS) * 4;
+constexpr int BWD_LDS = (9 * TC * TC + 2 * PADCELLS * TS + 7 * TC + 1024 + 4 * TC * PBS) * 4;
 std::atomic<unsigned long long> g_attr[8];
 template <class K> int big_lds(K kernel, int bytes, int slot) {
     return az_set_kernel_lds(reinterpret_cast<const void*>(kernel), bytes, g_attr[slot]);
