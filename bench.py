@@ -400,6 +400,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--model', default='c4_6x32', choices=['uniform', 'c4_6x32', 'c4_10x128'])
     ap.add_argument('--net-impl', default='hip', choices=['torch', 'hip'])
+    ap.add_argument('--net-precision', default='bf16', choices=['bf16', 'fp32'],
+                    help="c4_6x32 with --net-impl hip: 'fp32' times the one-launch kernel with the fp16-pair network "
+                         "(outputs within 1e-5 of the fp32 module) instead of the bf16 one")
     ap.add_argument('--games', type=int, default=8192)
     ap.add_argument('--sims', type=int, default=800)
     ap.add_argument('--preroll', type=int, default=24,
@@ -475,8 +478,11 @@ def main():
         torch.manual_seed(0)
         net = AlphaZeroC4(blocks, ch).to(dev).eval()
         if args.net_impl == 'hip':
-            from alphazero_amd.net import C4Net128, FusedC4Net
-            fused = FusedC4Net.from_module(net, dev) if ch <= 32 else C4Net128(net, dev, max_leaves=G)
+            from alphazero_amd.net import C4Net128, FusedC4Net, FusedC4NetHX
+            if ch <= 32:
+                fused = FusedC4NetHX(net, dev) if args.net_precision == 'fp32' else FusedC4Net.from_module(net, dev)
+            else:
+                fused = C4Net128(net, dev, max_leaves=G)
             evaluate = lambda bb, info: fused(bb, info)
         else:
             evaluate = lambda bb, info: evaluate_leaves(eng.game, net, bb, info)
@@ -583,7 +589,7 @@ def main():
     elapsed = time.perf_counter() - t0
     st1 = eng.stats()
     hits = (eng.eval_cache_hits() - hits0) if use_cache else 0
-    if fused_move and not multi:
+    if fused_move and not multi and args.net_precision == 'bf16':
         # untimed, single-GPU runs only: two moves through the per-simulation kernels, for their own durations (the search
         # kernel against HBM, the network kernel against the matrix cores)
         stepwise_now[0] = True
@@ -612,14 +618,17 @@ def main():
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * elapsed / args.steps,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f64 PUCT score, f32 W/P, u32 N' + ('' if net is None else '; net trunk bf16 MFMA, f32 accumulate'),
+        'dtype': 'f64 PUCT score, f32 W/P, u32 N' + ('' if net is None else (
+            '; net trunk fp16-pair operands (three f16 MFMAs per product), f32 accumulate: f32 grade'
+            if args.net_precision == 'fp32' and ch <= 32 and args.net_impl == 'hip' else '; net trunk bf16 MFMA, f32 accumulate')),
         'data': 'synthetic',
         'config': {'workload': f'connect4 self-play, {S} sims/move, {G} games/GPU, exploration_depth 4, '
                                f'reuse_search_tree, model {args.model}, {args.mix_moves} age-mixing moves + '
                                f'{args.preroll} pre-roll moves',
                    'games_per_gpu': G, 'sims_per_move': S, 'net': args.model,
                    'launches': 'one per move (az_c4_move_fused)' if fused_move else 'per simulation',
-                   'net_impl': None if net is None else args.net_impl, 'preroll_moves': args.preroll,
+                   'net_impl': None if net is None else args.net_impl,
+                   'net_precision': None if net is None else args.net_precision, 'preroll_moves': args.preroll,
                    'mix_moves': args.mix_moves,
                    'mean_select_depth': d, 'leaf_eval_fraction': f,
                    'eval_cache_log2': args.eval_cache_log2 if use_cache else 0,
@@ -655,9 +664,12 @@ def main():
             ms = avg_ms(move_ev)
             fl = trunk_flops_per_leaf(blocks, ch) * (evals - hits) / args.steps
             tf = fl / (ms * 1e-3) / 1e12
-            out['roofline'] = {'kernel': 'k_c4_move_fused', 'bound': 'mfma', 'achieved': tf, 'peak': BF16_PEAK_TFLOPS,
-                               'unit': 'TFLOP/s', 'frac': tf / BF16_PEAK_TFLOPS,
-                               'traffic': pmc_traffic('k_c4_move_fused'), 'avg_launch_ms': ms,
+            hx_run = args.net_precision == 'fp32'
+            issued = 3.0 if hx_run else 1.0              # MFMAs issued per product
+            out['roofline'] = {'kernel': 'k_c4_move_fused<fp16 pairs>' if hx_run else 'k_c4_move_fused', 'bound': 'mfma',
+                               'achieved': tf, 'peak': BF16_PEAK_TFLOPS,
+                               'unit': 'TFLOP/s', 'frac': issued * tf / BF16_PEAK_TFLOPS, 'mfma_issued_tflops': issued * tf,
+                               'traffic': None if hx_run else pmc_traffic('k_c4_move_fused'), 'avg_launch_ms': ms,
                                'flops_per_leaf': trunk_flops_per_leaf(blocks, ch),
                                'leaves_per_launch': (evals - hits) / args.steps,
                                'note': 'all simulations of a move: tree walks and network tasks of different games '
@@ -689,7 +701,7 @@ def main():
             out['roofline'] = {'kernel': 'k_run_uniform<GameC4>', 'bound': 'hbm', 'achieved': gbs,
                                'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
                                'traffic': None, 'avg_launch_ms': ms, 'bytes_per_sim': bps}
-        if not multi and fused_move and not args.no_extras:
+        if not multi and fused_move and not args.no_extras and args.net_precision == 'bf16':
             from alphazero_amd.net import FusedC4NetF32
             f32 = FusedC4NetF32(net, dev)
             def extra(name, fn):

@@ -12,12 +12,13 @@ import sys
 out = sys.argv[1]
 summ = os.path.join(out, 'summary')
 os.makedirs(summ, exist_ok=True)
-for name in ('bench_net', 'bench_net_stepwise', 'bench_net_cache', 'bench_uniform', 'net128'):
+for name in ('bench_net', 'bench_net_fp32', 'train_step', 'bench_net_stepwise', 'bench_net_cache', 'bench_uniform', 'net128'):
     for f in glob.glob(os.path.join(out, name, '*', '*kernel_stats.csv')):
         shutil.copy(f, os.path.join(summ, f'{name}_kernel_stats.csv'))
     log = os.path.join(out, name + '.log')
     if os.path.exists(log):
-        lines = [l for l in open(log, errors='replace').read().splitlines() if l.startswith('{') or l.startswith('10x128')]
+        lines = [l for l in open(log, errors='replace').read().splitlines()
+                 if l.startswith('{') or l.startswith('10x128') or l.startswith('eager:') or l.startswith('graph:')]
         open(os.path.join(summ, f'{name}_run.txt'), 'w').write('\n'.join(lines) + '\n')
 pmc = {}
 for d in sorted(glob.glob(os.path.join(out, 'pmc*'))):
