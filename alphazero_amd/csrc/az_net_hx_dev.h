@@ -289,25 +289,40 @@ __device__ __forceinline__ void hx_heads_own(const uint8_t* blob, const float* s
     const f32x4* w1 = reinterpret_cast<const f32x4*>(blob + HX_OFF_W1) + lane;
     f32x4 hsum = reinterpret_cast<const f32x4*>(blob + HX_OFF_B1)[lane];
     const f32x4 w2 = reinterpret_cast<const f32x4*>(blob + HX_OFF_W2)[lane];
+#ifdef HX_PARTIAL_WAIT
+    // diagnostic build (tools/exp_lds_wait_probe.py): the loop as first written, waits left to the compiler
+#pragma unroll 6
+    for (int c = 0; c < 42; ++c) {
+        const f32x4 wv = w1[c * 64];
+        const float a = strip[84 + c];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) hsum[u] = fmaf(wv[u], a, hsum[u]);
+    }
+#else
 #pragma unroll 1
-    for (int c0 = 0; c0 < 42; c0 += 6) {
-        f32x4 wv[6];
-        float av[6];
+    for (int c0 = 0; c0 < 42; c0 += 21) {                  // two trips to L2 of 21 rows each
+        f32x4 wv[21];
+        float av[21];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) wv[j] = w1[(c0 + j) * 64];
+        for (int j = 0; j < 21; ++j) wv[j] = w1[(c0 + j) * 64];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) av[j] = strip[84 + c0 + j];
-        // All six plane values are waited for together.  Left to the compiler, the six floats arrive as one 128-bit
+        for (int j = 0; j < 21; ++j) av[j] = strip[84 + c0 + j];
+        // All plane values of a trip are waited for together.  Left to the compiler, six floats arrived as one 128-bit
         // and one 64-bit LDS read with a partial wait (lgkmcnt(1)) in between, and with the SIMD's other wave
         // issuing MFMAs the first read's data was seen stale in lanes 48..63 by the packed multiply-adds that
         // followed (one hidden unit in seven boards wrong, differently from run to run); with the full wait
         // every run gives the same, correct bits.
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(av[4]), "+v"(av[5]) :: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(av[4]), "+v"(av[5]), "+v"(av[6]), "+v"(av[7]),
+                       "+v"(av[8]), "+v"(av[9]), "+v"(av[10]), "+v"(av[11]), "+v"(av[12]), "+v"(av[13]), "+v"(av[14]),
+                       "+v"(av[15]), "+v"(av[16]), "+v"(av[17]), "+v"(av[18]), "+v"(av[19]), "+v"(av[20])
+                     :: "memory");
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
+        for (int j = 0; j < 21; ++j)
 #pragma unroll
             for (int u = 0; u < 4; ++u) hsum[u] = fmaf(wv[j][u], av[j], hsum[u]);
     }
+#endif
     float part = 0.0f;
 #pragma unroll
     for (int u = 0; u < 4; ++u) part = fmaf(fmaxf(hsum[u], 0.0f), w2[u], part);
