@@ -59,7 +59,7 @@ class TrainingWorker:
         self._draw = None
         if (torch.device(device).type == 'cuda' and hasattr(dataset, 'kernel_sampling')
                 and dataset.kernel_sampling(self._batch_size)):
-            self._sample_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            self._sample_seed = None           # drawn from torch's generator at the first batch (see _seed())
             self._draw = torch.zeros(1, dtype=torch.int64, device=device)
         # the hand-written pass binds the parameters and their .grad tensors where FlatSGD has put them
         self._hand = None
@@ -73,11 +73,18 @@ class TrainingWorker:
     def model(self):
         return self._model
 
+    def _seed(self):
+        # taken when the first batch is drawn, not at construction: a data-parallel job seeds every rank alike for
+        # the initial weights and differently afterwards for the sample streams (train.synchronous_play_and_train)
+        if self._sample_seed is None:
+            self._sample_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        return self._sample_seed
+
     def _batch(self):
         if hasattr(self._dataset, 'sample'):
             # DeviceReplayWindow: the window already lives on the GPU as tensors
             if self._draw is not None:
-                b = self._dataset.sample(self._batch_size, seed=self._sample_seed, draw_dev=self._draw)
+                b = self._dataset.sample(self._batch_size, seed=self._seed(), draw_dev=self._draw)
             else:
                 b = self._dataset.sample(self._batch_size)
             return (b['x'].to(self._device), b['p'].to(self._device), b['z'].to(self._device),
@@ -163,6 +170,7 @@ class TrainingWorker:
         self._gz = torch.empty((B,) + tuple(ds.z.shape[1:]), dtype=ds.z.dtype, device=dev)
         self._gvalid = torch.empty((B,) + tuple(ds.p_valid.shape[1:]), dtype=ds.p_valid.dtype, device=dev)
         in_graph = self._draw is not None
+        seed = self._seed() if in_graph else None
         if not in_graph:
             ds.sample_into(self._gx, self._gp, self._gz, self._gvalid)
         self._sample_in_graph = in_graph
@@ -171,7 +179,7 @@ class TrainingWorker:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             if in_graph:
-                ds.sample_into(self._gx, self._gp, self._gz, self._gvalid, seed=self._sample_seed, draw_dev=self._draw)
+                ds.sample_into(self._gx, self._gp, self._gz, self._gvalid, seed=seed, draw_dev=self._draw)
             if self._hand is not None:
                 out3 = self._hand.run(self._gx, self._gp, self._gz, self._gvalid)
                 policy_loss, value_loss, guard = out3[0], out3[1], out3[2:3]

@@ -644,15 +644,19 @@ def main():
         def avg_ms(pairs):
             return sum(a.elapsed_time(b) for a, b in pairs) / len(pairs)
 
-        def pmc_traffic(kernel_prefix):
+        def pmc_traffic(*kernel_prefixes):
             """HBM bytes per launch from the newest committed counter passes of this same command
             (profiles/rNN_pmc_means.json: FETCH_SIZE and WRITE_SIZE in KiB, separate passes;
-            FETCH_SIZE doubled, the gfx950 correction for 16-byte-per-lane reads)."""
+            FETCH_SIZE doubled, the gfx950 correction for 16-byte-per-lane reads).  A kernel is named by the
+            start of its signature, with or without the leading return type."""
+            def named(k):
+                k = k[5:] if k.startswith('void ') else k
+                return any(k.startswith(p[5:] if p.startswith('void ') else p) for p in kernel_prefixes)
             try:
                 pm = json.load(open(latest_profile('pmc_means.json')))
                 for fk, wk in (('pmc_fetch', 'pmc_write'), ('pmc_stepwise_fetch', 'pmc_stepwise_write')):
-                    fe = [v['FETCH_SIZE']['mean'] for k, v in pm.get(fk, {}).items() if k.startswith(kernel_prefix)]
-                    wr = [v['WRITE_SIZE']['mean'] for k, v in pm.get(wk, {}).items() if k.startswith(kernel_prefix)]
+                    fe = [v['FETCH_SIZE']['mean'] for k, v in pm.get(fk, {}).items() if named(k)]
+                    wr = [v['WRITE_SIZE']['mean'] for k, v in pm.get(wk, {}).items() if named(k)]
                     if fe and wr:
                         return (2.0 * fe[0] + wr[0]) * 1024.0
                 return None
@@ -669,7 +673,7 @@ def main():
             out['roofline'] = {'kernel': 'k_c4_move_fused<fp16 pairs>' if hx_run else 'k_c4_move_fused', 'bound': 'mfma',
                                'achieved': tf, 'peak': BF16_PEAK_TFLOPS,
                                'unit': 'TFLOP/s', 'frac': issued * tf / BF16_PEAK_TFLOPS, 'mfma_issued_tflops': issued * tf,
-                               'traffic': None if hx_run else pmc_traffic('k_c4_move_fused'), 'avg_launch_ms': ms,
+                               'traffic': None if hx_run else pmc_traffic('k_c4_move_fused<false>', 'k_c4_move_fused('), 'avg_launch_ms': ms,
                                'flops_per_leaf': trunk_flops_per_leaf(blocks, ch),
                                'leaves_per_launch': (evals - hits) / args.steps,
                                'note': 'all simulations of a move: tree walks and network tasks of different games '
