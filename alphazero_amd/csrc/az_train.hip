@@ -14,6 +14,7 @@
 
 #include "../../include/azhip.h"
 #include "az_host.h"
+#include "az_loss_dev.h"
 
 // One workgroup, thread = sample (strided): deterministic sums, and the batches of this path are small
 // (config/connectfour.yaml: 128).  A <= AZ_MAX_ACTIONS.
@@ -26,41 +27,12 @@ k_loss(const float* __restrict__ logits, const float* __restrict__ v_hat, const 
     float pl = 0.0f, vl = 0.0f, dev = 0.0f;
     const float invB = 1.0f / (float)B;
     for (int b = threadIdx.x; b < B; b += 256) {
-        float m = -INFINITY;
-        for (int a = 0; a < A; ++a) if (valid[(size_t)b * A + a]) m = fmaxf(m, logits[(size_t)b * A + a]);
-        float sum = 0.0f, tsum = 0.0f;
-        for (int a = 0; a < A; ++a) {
-            if (valid[(size_t)b * A + a]) sum += expf(logits[(size_t)b * A + a] - m);
-            tsum += target[(size_t)b * A + a];
-        }
-        const float lse = m + logf(sum);
-        float ce = 0.0f, tvalid = 0.0f;
-        for (int a = 0; a < A; ++a) {
-            const bool ok = valid[(size_t)b * A + a];
-            const float t = target[(size_t)b * A + a];
-            if (ok && t != 0.0f) { ce -= t * (logits[(size_t)b * A + a] - lse); tvalid += t; }   // loss.py:29-47
-        }
-        for (int a = 0; a < A; ++a) {
-            const bool ok = valid[(size_t)b * A + a];
-            const float t = target[(size_t)b * A + a];
-            const float q = ok ? expf(logits[(size_t)b * A + a] - lse) : 0.0f;
-            dlogits[(size_t)b * A + a] = ok ? (q * tvalid - (t != 0.0f ? t : 0.0f)) * invB : 0.0f;
-        }
-        const float d = v_hat[b] - z[b];
-        dv[b] = 2.0f * d * invB;                                                               // loss.py:57
-        pl += ce; vl += d * d;
-        dev = fmaxf(dev, fabsf(tsum - 1.0f));
+        float ce, sq, dv1;
+        loss_sample<A>(logits, v_hat, target, z, valid, b, invB, dlogits, dv, ce, sq, dv1);
+        pl += ce; vl += sq;
+        dev = fmaxf(dev, dv1);
     }
-    red[0][threadIdx.x] = pl; red[1][threadIdx.x] = vl; red[2][threadIdx.x] = dev;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) {
-            red[0][threadIdx.x] += red[0][threadIdx.x + s];
-            red[1][threadIdx.x] += red[1][threadIdx.x + s];
-            red[2][threadIdx.x] = fmaxf(red[2][threadIdx.x], red[2][threadIdx.x + s]);
-        }
-        __syncthreads();
-    }
+    loss_totals(pl, vl, dev, red);
     if (threadIdx.x == 0) { out[0] = red[0][0] * invB; out[1] = red[1][0] * invB; out[2] = red[2][0]; }
 }
 
@@ -132,23 +104,37 @@ k_sample_window(const float* __restrict__ wx, const float* __restrict__ wp, cons
     const long long count = count_dev[0];
     const int n = count < capacity ? (int)count : capacity;
     const unsigned long long draw = (unsigned long long)draw_dev[0];
+    __shared__ int repeated;
+    // Uniform without replacement while the window holds at least a batch (each draw is rejected while it repeats an
+    // earlier one), with replacement otherwise (alphazero/replay_buffer.py:188-195).  Every sample's first draw is made
+    // in parallel; only when two of them coincide (one batch in six for 128 of 50 000 states) does thread 0 go through
+    // the samples in order, which is what defines the result in both cases.
+    const bool distinct = batch <= n;
     for (int i = tid; i < (n + 31) / 32; i += 256) taken[i] = 0u;
+    if (tid == 0) repeated = 0;
     __syncthreads();
-    if (tid == 0) {
-        // uniform without replacement while the window holds at least a batch (each draw is rejected while it repeats
-        // an earlier one), with replacement otherwise (alphazero/replay_buffer.py:188-195)
-        const bool distinct = batch <= n;
-        for (int i = 0; i < batch; ++i) {
-            uint32_t r, attempt = 0;
-            for (;;) {
-                r = (uint32_t)(((uint64_t)mix32(seed, draw, (uint32_t)i, attempt++) * (uint64_t)n) >> 32);
-                if (!distinct || !((taken[r >> 5] >> (r & 31)) & 1u)) break;
-            }
-            taken[r >> 5] |= 1u << (r & 31);
-            pick[i] = (int)(((long long)r + (count - n)) % capacity);       // the i-th oldest state sits at (count - n + i) % capacity
-        }
-        draw_dev[0] = (long long)(draw + 1);
+    for (int i = tid; i < batch; i += 256) {
+        const uint32_t r = (uint32_t)(((uint64_t)mix32(seed, draw, (uint32_t)i, 0) * (uint64_t)n) >> 32);
+        if (distinct && ((atomicOr(&taken[r >> 5], 1u << (r & 31)) >> (r & 31)) & 1u)) repeated = 1;
+        pick[i] = (int)(((long long)r + (count - n)) % capacity);           // the i-th oldest state sits at (count - n + i) % capacity
     }
+    __syncthreads();
+    if (repeated) {
+        for (int i = tid; i < (n + 31) / 32; i += 256) taken[i] = 0u;
+        __syncthreads();
+        if (tid == 0) {
+            for (int i = 0; i < batch; ++i) {
+                uint32_t r, attempt = 0;
+                for (;;) {
+                    r = (uint32_t)(((uint64_t)mix32(seed, draw, (uint32_t)i, attempt++) * (uint64_t)n) >> 32);
+                    if (!((taken[r >> 5] >> (r & 31)) & 1u)) break;
+                }
+                taken[r >> 5] |= 1u << (r & 31);
+                pick[i] = (int)(((long long)r + (count - n)) % capacity);
+            }
+        }
+    }
+    if (tid == 0) draw_dev[0] = (long long)(draw + 1);
     __syncthreads();
     for (int i = tid; i < batch * x_floats; i += 256) x[i] = wx[(size_t)pick[i / x_floats] * x_floats + i % x_floats];
     for (int i = tid; i < batch * A; i += 256) {

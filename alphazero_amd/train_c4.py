@@ -50,10 +50,14 @@ def supports(model):
 
 
 class C4TrainStep:
-    def __init__(self, model):
+    """`chain=True` runs the pass as a chain of launches, one step each (az_c4_train_fwd_bwd_chain); by default the
+    library takes the one-launch form whenever the batch fits the device (az_c4_train_fwd_bwd).  Same bits either way."""
+
+    def __init__(self, model, chain=False):
         if not supports(model):
             raise ValueError('C4TrainStep: AlphaZeroC4 with 32 trunk channels on a GPU')
         self.lib = _lib.load()
+        self._entry = self.lib.az_c4_train_fwd_bwd_chain if chain else self.lib.az_c4_train_fwd_bwd
         self.model = model
         self.device = next(model.parameters()).device
         self._ws = None
@@ -107,6 +111,13 @@ class C4TrainStep:
         n.val_fc2_b, n.val_fc2_b_grad = vh._fc[2].bias.data_ptr(), grad(vh._fc[2].bias)
         self.net = n
 
+    def one_launch_max_batch(self):
+        """Largest batch the one-launch form takes on this device (one board per compute unit)."""
+        n = C.c_int32()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.az_c4_train_one_launch_max_batch(self.model.num_blocks, C.byref(n)))
+        return int(n.value)
+
     def run(self, x, p, z, p_valid):
         """x float32 [B,2,6,7], p float32 [B,7], z float32 [B] or [B,1], p_valid bool / uint8 [B,7] (all on the
         module's device, contiguous).  Returns self.out3; self.logits [B,7] and self.v_hat [B] hold the outputs."""
@@ -123,7 +134,7 @@ class C4TrainStep:
             self._batch = B
         with torch.cuda.device(self.device):
             st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-            _lib.check(self.lib.az_c4_train_fwd_bwd(C.byref(self.net), _lib.ptr(x), _lib.ptr(p_valid), _lib.ptr(p), _lib.ptr(z),
+            _lib.check(self._entry(C.byref(self.net), _lib.ptr(x), _lib.ptr(p_valid), _lib.ptr(p), _lib.ptr(z),
                                                     B, _lib.ptr(self._ws), _lib.ptr(self.out3), _lib.ptr(self.logits),
                                                     _lib.ptr(self.v_hat), st))
         return self.out3

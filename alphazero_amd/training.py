@@ -124,7 +124,8 @@ class TrainingWorker:
         if N < M:
             print(f'Skipping batch, too few examples in replay buffer ({N} < {M}).')
             return 0
-        self._model.train()
+        if not self._model.training:                   # (walking the module tree costs 0.1 ms: only when it changes anything)
+            self._model.train()
         if self._record and self._iter >= self.EAGER_STEPS:
             return self._process_batch_recorded()
         x, p, z, p_valid, extra = self._batch()
@@ -183,7 +184,7 @@ class TrainingWorker:
             if self._hand is not None:
                 out3 = self._hand.run(self._gx, self._gp, self._gz, self._gvalid)
                 policy_loss, value_loss, guard = out3[0], out3[1], out3[2:3]
-                total = policy_loss + value_loss
+                total = None                           # (added up when somebody logs it: one launch less per step)
             else:
                 p_hat, v_hat = self._model(self._gx, self._gvalid)
                 policy_loss, value_loss = self._loss(self._gp, self._gz, p_hat, v_hat, self._gvalid)
@@ -195,7 +196,7 @@ class TrainingWorker:
             # that fails it changes no weight (the reference asserts before optimizer.step(), loss.py:58-59)
             self._optimizer.step_recorded(guard=guard)
         self._graph = graph
-        self._g_out = (policy_loss.detach(), value_loss.detach(), total.detach())
+        self._g_out = (policy_loss.detach(), value_loss.detach(), None if total is None else total.detach())
         return graph
 
     def _process_batch_recorded(self):
@@ -218,6 +219,8 @@ class TrainingWorker:
             assert withheld == 0, f'Target policy must be a valid distribution ({withheld} update(s) withheld)'
         if self._writer is not None:
             policy_loss, value_loss, total = self._g_out
+            if total is None:
+                total = policy_loss + value_loss
             self._writer.add_scalar('loss/policy', policy_loss, it)
             self._writer.add_scalar('loss/value', value_loss, it)
             self._writer.add_scalar('loss/total', total, it)

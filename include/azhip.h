@@ -291,11 +291,23 @@ typedef struct az_c4_train_net {
 long az_c4_train_workspace_bytes(int32_t batch, int32_t num_blocks);
 /* x float [batch][2][6][7] (ConnectFour.render planes), valid uint8 [batch][7], target_p float [batch][7], z float
  * [batch]; out3 DEVICE float[3] = {policy loss, value loss, max |sum(target) - 1|} as az_loss_fwd_bwd;
- * logits7_out [batch][7] / vhat_out [batch] receive the network's outputs when not NULL.  4 * num_blocks + 11
- * launches on `stream`, no allocation, no host synchronisation (it can be recorded in a HIP graph).  batch >= 2. */
+ * logits7_out [batch][7] / vhat_out [batch] receive the network's outputs when not NULL.  No allocation, no host
+ * synchronisation (it can be recorded in a HIP graph).  batch >= 2.
+ * Two launches on `stream` when the batch fits the device with one board per compute unit
+ * (az_c4_train_one_launch_max_batch): the weights' re-ordering and ONE launch for forward, loss, backward and the
+ * batch sums, whose workgroups exchange the batch statistics among themselves; it needs all `batch` workgroups
+ * resident, waits about a second for a workgroup that does not arrive and then ends with out3 = {NaN, NaN, +inf}
+ * and no gradient to be used.  Larger batches, or AZ_TRAIN_CHAIN=1 in the environment: the chain below.          */
 int  az_c4_train_fwd_bwd(const az_c4_train_net* net, const float* x, const uint8_t* valid, const float* target_p,
                          const float* z, int32_t batch, void* workspace, float* out3, float* logits7_out,
                          float* vhat_out, void* stream);
+/* the same pass as a chain of 4 * num_blocks + 11 launches, one step each, the launch boundaries as the only
+ * synchronisation: any batch size, the same bits as the one-launch form                                          */
+int  az_c4_train_fwd_bwd_chain(const az_c4_train_net* net, const float* x, const uint8_t* valid, const float* target_p,
+                               const float* z, int32_t batch, void* workspace, float* out3, float* logits7_out,
+                               float* vhat_out, void* stream);
+/* largest batch the one-launch form takes on the current device for this depth (0: none)                        */
+int  az_c4_train_one_launch_max_batch(int32_t num_blocks, int32_t* max_batch);
 
 /* ---- fused Connect Four network forward (K8/K12) ---------------------------
  * Whole AlphaZeroC4 forward (alphazero/models.py:70-87, connectfour.py:54-72) for n

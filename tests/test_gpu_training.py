@@ -245,9 +245,11 @@ def test_recorded_step_withholds_the_update_of_a_bad_batch(channels):
     assert torch.equal(oa.flat_p, ob.flat_p) and int(ob.withheld) == 0
 
 
-@pytest.mark.parametrize('blocks,B', [(6, 128), (1, 16), (0, 8), (2, 77)])
-def test_hand_written_training_pass_matches_torch_autograd(blocks, B):
-    """az_c4_train_fwd_bwd (forward in training mode, AlphaZeroLoss, backward: no vendor convolution, no autograd)
+@pytest.mark.parametrize('blocks,B,chain', [(6, 128, False), (6, 128, True), (1, 16, False), (0, 8, False), (2, 77, True),
+                                             (2, 300, False)])
+def test_hand_written_training_pass_matches_torch_autograd(blocks, B, chain):
+    """az_c4_train_fwd_bwd (forward in training mode, AlphaZeroLoss, backward: no vendor convolution, no autograd; one
+    launch for the whole pass, or -- chain, and any batch beyond one board per compute unit -- one launch per step)
     against the torch statement of alphazero/training.py:57-71 evaluated in float64 on the same GPU: losses and
     network outputs within 1e-5, running statistics and counters as torch leaves them, every gradient within 1e-4 of
     its tensor's scale on the first pass and within 5e-3 on the two passes after an SGD step: there a float32
@@ -268,7 +270,7 @@ def test_hand_written_training_pass_matches_torch_autograd(blocks, B):
     model = model.cuda().train()
     ref32, ref = copy.deepcopy(model), copy.deepcopy(model).double()
     assert supports(model)
-    step = C4TrainStep(model)
+    step = C4TrainStep(model, chain=chain)
     rng = np.random.RandomState(blocks * 7 + B)
     for it in range(3):
         hists = _random_positions(B, 50 + it)
@@ -317,6 +319,58 @@ def test_hand_written_training_pass_matches_torch_autograd(blocks, B):
                 a.add_(g, alpha=-0.05)
                 c.add_(g, alpha=-0.05)
                 b.copy_(a.double())
+
+
+def _c4_batch(B, seed, rng):
+    from alphazero_amd import engine as E
+    from test_gpu_net import _random_positions
+    bb, nm = E.positions_from_history(1, _random_positions(B, seed))
+    x, valid = E.render(1, bb)
+    x, valid = x.contiguous(), valid.contiguous()
+    t = rng.random_sample((B, 7)).astype(np.float32) * valid.cpu().numpy()
+    t /= t.sum(1, keepdims=True)
+    p = torch.from_numpy(t.astype(np.float32)).cuda()
+    z = torch.from_numpy(rng.choice([-1.0, 0.0, 1.0], size=(B, 1)).astype(np.float32)).cuda()
+    return x, p, z, valid
+
+
+@pytest.mark.parametrize('blocks,B', [(6, 128), (1, 16), (0, 8), (2, 77), (3, 256), (6, 2)])
+def test_one_launch_training_pass_equals_the_chain_of_launches(blocks, B):
+    """The two forms of az_c4_train_fwd_bwd run the same steps with the same thread-to-data mapping and differ only in
+    how the boards' partial sums travel between steps (tagged pairs polled inside one resident grid / rows read after
+    a launch boundary): losses, outputs, every gradient and every batch-norm buffer are equal bit for bit, over three
+    passes with an SGD step in between (a stale row of the previous pass or step would show)."""
+    import copy
+    from alphazero_amd.models import AlphaZeroC4
+    from alphazero_amd.train_c4 import C4TrainStep
+    from test_gpu_net import _randomize_bn
+    torch.manual_seed(200 + blocks)
+    model = AlphaZeroC4(blocks, 32)
+    _randomize_bn(model, 3)
+    with torch.no_grad():
+        model._policy_head._fc.bias.uniform_(-0.1, 0.1)
+        model._value_head._fc[2].bias.uniform_(-0.1, 0.1)
+    one = model.cuda().train()
+    chain = copy.deepcopy(one)
+    s_one, s_chain = C4TrainStep(one), C4TrainStep(chain, chain=True)
+    assert s_one.one_launch_max_batch() >= B
+    rng = np.random.RandomState(blocks * 7 + B)
+    for it in range(3):
+        x, p, z, valid = _c4_batch(B, 60 + it, rng)
+        a = s_one.run(x, p, z, valid).clone()
+        b = s_chain.run(x, p, z, valid).clone()
+        torch.cuda.synchronize()
+        assert torch.isfinite(a).all(), a
+        assert torch.equal(a, b), (it, a, b)
+        assert torch.equal(s_one.logits, s_chain.logits) and torch.equal(s_one.v_hat, s_chain.v_hat)
+        for (name, u), (_, v) in zip(one.named_parameters(), chain.named_parameters()):
+            assert torch.equal(u.grad, v.grad), (it, name, (u.grad - v.grad).abs().max().item())
+        for (name, u), (_, v) in zip(one.named_buffers(), chain.named_buffers()):
+            assert torch.equal(u, v), (it, name)
+        with torch.no_grad():
+            for u, v in zip(one.parameters(), chain.parameters()):
+                u.add_(u.grad, alpha=-0.05)
+                v.add_(v.grad, alpha=-0.05)
 
 
 def test_training_worker_with_the_hand_written_pass_follows_the_torch_path(monkeypatch):
