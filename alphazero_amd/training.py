@@ -3,7 +3,7 @@
 cross-entropy + MSE, weights published after every step.  On the GPU the loss with its gradients and the
 optimiser update are hand-written kernels (loss.AlphaZeroLoss, optim.FlatSGD; csrc/az_train.hip).  For the
 Connect Four network with 32 trunk channels the whole pass -- forward on the batch's statistics, loss, backward,
-running statistics -- is hand-written too (train_c4.C4TrainStep, csrc/az_train_c4.hip: 35 launches for six blocks,
+running statistics -- is hand-written too (train_c4.C4TrainStep, csrc/az_train_c4.hip: one resident launch,
 no vendor convolution, no autograd; AZ_TRAIN_HANDWRITTEN=0 switches it off); other networks go through PyTorch's
 forward and backward.  With a DeviceReplayWindow on the GPU the whole step is recorded once as a HIP graph after
 three ordinary steps and replayed from then on, the batch gathered into fixed tensors and the learning rate read
