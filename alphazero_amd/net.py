@@ -115,9 +115,38 @@ def _f32_bytes(t, pad_to=None):
     return t.contiguous().view(torch.uint8)
 
 
-def pack_c4_blob(model):
-    """AlphaZeroC4 module -> uint8 tensor (on the module's device) in the layout of
-    csrc/az_net.hip.  A handful of tensor ops, so it can run after every weight broadcast."""
+def pack_c4_blob(model, out=None):
+    """AlphaZeroC4 module -> uint8 tensor (on the module's device) in the layout of csrc/az_net.hip; into `out` when
+    given.  On a GPU it is one launch (az_c4net_pack_bf16), cheap enough to run after every optimiser step; a module on
+    the CPU goes through the tensor operations of _pack_c4_blob_torch, which state the same layout and give the same
+    bytes (tests/test_gpu_net.py)."""
+    dev = model._cbr[0].weight.device
+    if dev.type != 'cuda' or any(t.dtype != torch.float32 or not t.is_contiguous() for t in model.parameters()):
+        blob = _pack_c4_blob_torch(model)
+        if out is not None:
+            out.copy_(blob)
+            return out
+        return blob
+    C_ = model.block_channels
+    if C_ > CMAX:
+        raise ValueError(f'fused kernel supports up to {CMAX} trunk channels, got {C_}')
+    if tuple(model.shape_in) != (2, 6, 7):
+        raise ValueError('fused kernel is for Connect Four (2x6x7 input)')
+    from .train_c4 import param_struct
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(lib.az_c4net_blob_bytes(), dtype=torch.uint8, device=dev)
+    assert out.is_contiguous() and out.dtype == torch.uint8 and out.numel() == lib.az_c4net_blob_bytes() and out.device == dev
+    keep = []
+    net = param_struct(model, keep)
+    eps = float(model._cbr[1].eps)
+    assert all(float(m.eps) == eps for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d))
+    _launch(_device(dev), lambda st: lib.az_c4net_pack_bf16(C.byref(net), C_, C.c_double(eps), ptr(out), st))
+    return out
+
+
+def _pack_c4_blob_torch(model):
+    """The packed layout of csrc/az_net.hip stated in tensor operations (some 150 small launches on a GPU)."""
     C_ = model.block_channels
     if C_ > CMAX:
         raise ValueError(f'fused kernel supports up to {CMAX} trunk channels, got {C_}')
@@ -196,7 +225,10 @@ class FusedC4Net:
 
     def load_module(self, model):
         """Refresh the packed weights from `model` (after a weight broadcast / optimiser step)."""
-        self.blob.copy_(pack_c4_blob(model))
+        if next(model.parameters()).device == self.blob.device:
+            pack_c4_blob(model, out=self.blob)
+        else:
+            self.blob.copy_(pack_c4_blob(model))
         self.num_blocks = model.num_blocks
 
     def __call__(self, leaf_bb, leaf_info):

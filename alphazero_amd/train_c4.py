@@ -35,6 +35,34 @@ class TrainNet(C.Structure):
                 ('val_fc2_b', C.c_void_p), ('val_fc2_b_grad', C.c_void_p)]
 
 
+def param_struct(model, keep):
+    """az_c4_train_net with the module's parameters and batch-norm buffers and no gradient pointers: what
+    az_c4net_pack_bf16 reads.  Tensors made on the way (the stand-ins of a tower-less network) are appended to `keep`."""
+    m = model
+
+    def bn(mod):
+        return _Bn(mod.weight.data_ptr(), mod.bias.data_ptr(), mod.running_mean.data_ptr(), mod.running_var.data_ptr(),
+                   mod.num_batches_tracked.data_ptr(), 0, 0)
+    for t in list(m.parameters()) + list(m.buffers()):
+        assert t.is_contiguous()
+    n = TrainNet()
+    n.num_blocks = m.num_blocks
+    some_bn = m._cbr[1]
+    n.bn_momentum, n.bn_eps = float(some_bn.momentum or 0.0), float(some_bn.eps)
+    n.stem_w, n.stem_bn = m._cbr[0].weight.data_ptr(), bn(m._cbr[1])
+    if m.num_blocks:
+        blk = m._tower[0]
+        n.c1_w, n.bn1 = blk._c1.weight.data_ptr(), bn(blk._bn1)
+        n.c2_w, n.bn2 = blk._c2.weight.data_ptr(), bn(blk._bn2)
+    ph, vh = m._policy_head, m._value_head
+    n.pol_conv_w, n.pol_conv_b, n.pol_bn = ph._cbr[0].weight.data_ptr(), ph._cbr[0].bias.data_ptr(), bn(ph._cbr[1])
+    n.pol_fc_w, n.pol_fc_b = ph._fc.weight.data_ptr(), ph._fc.bias.data_ptr()
+    n.val_conv_w, n.val_bn = vh._cbr[0].weight.data_ptr(), bn(vh._cbr[1])
+    n.val_fc1_w, n.val_fc1_b = vh._fc[0].weight.data_ptr(), vh._fc[0].bias.data_ptr()
+    n.val_fc2_w, n.val_fc2_b = vh._fc[2].weight.data_ptr(), vh._fc[2].bias.data_ptr()
+    return n
+
+
 def supports(model):
     """True for the network these kernels are written for: AlphaZeroC4 (2x6x7 -> 6x7) with 32 trunk channels, default
     batch-norm settings, on a GPU."""

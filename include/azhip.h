@@ -316,6 +316,13 @@ int  az_c4_train_one_launch_max_batch(int32_t num_blocks, int32_t* max_batch);
  * columns, mcts.py:106) and v float[n].  blob = DEVICE buffer of az_c4net_blob_bytes()
  * bytes packed by alphazero_amd/net.py (layout in csrc/az_net.hip).               */
 int  az_c4net_blob_bytes(void);
+/* The module's parameters -> the packed weights of az_c4net_bf16_forward / az_c4_move_fused, in one launch: eval-mode
+ * batch-norm (running statistics, bn_eps) folded into the convs in double, rounded to float and then to bf16 -- the
+ * bytes alphazero_amd.net._pack_c4_blob_torch produces with tensor operations.  `net` as for az_c4_train_fwd_bwd (the
+ * *_grad and num_batches_tracked members are not read); channels = the trunk's width, 1..32; blob DEVICE
+ * [az_c4net_blob_bytes()].  This is what reaches the self-play kernels after every published model
+ * (alphazero/selfplay.py:16-22 pulls the latest weights before each game).                                         */
+int  az_c4net_pack_bf16(const az_c4_train_net* net, int32_t channels, double bn_eps, uint8_t* blob, void* stream);
 int  az_c4net_bf16_forward(const uint8_t* blob, int32_t num_blocks, const uint64_t* leaf_bb,
                            const int32_t* leaf_info, int32_t n, float* p, float* v, void* stream);
 

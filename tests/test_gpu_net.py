@@ -451,3 +451,35 @@ def test_tictactoe_kernel_reproduces_the_reference_outputs():
             assert abs(v[i] - v_ref) <= 1e-6 + 1e-5 * abs(v_ref)
             checked += 1
     assert checked > 50
+
+
+@pytest.mark.parametrize('blocks,channels', [(6, 32), (2, 16), (0, 32), (3, 8), (1, 20)])
+def test_packing_kernel_writes_the_bytes_of_the_tensor_statement(blocks, channels):
+    """az_c4net_pack_bf16 (one launch: batch-norm folded in double, float, bf16, fragment layout) against
+    net._pack_c4_blob_torch, the same layout in tensor operations: equal byte for byte, also after the weights and the
+    running statistics have moved (FusedC4Net.load_module packs in place)."""
+    from alphazero_amd.models import AlphaZeroC4
+    from alphazero_amd.net import FusedC4Net, _pack_c4_blob_torch, pack_c4_blob
+    torch.manual_seed(7 * blocks + channels)
+    model = AlphaZeroC4(blocks, channels)
+    _randomize_bn(model, blocks + channels)
+    with torch.no_grad():
+        model._policy_head._fc.bias.uniform_(-0.1, 0.1)
+        model._value_head._fc[2].bias.uniform_(-0.1, 0.1)
+        model._policy_head._cbr[0].bias.uniform_(-0.2, 0.2)
+    model = model.cuda().eval()
+    want = _pack_c4_blob_torch(model)
+    got = pack_c4_blob(model)
+    assert got.dtype == torch.uint8 and got.shape == want.shape
+    diff = (got != want).nonzero().reshape(-1)
+    assert diff.numel() == 0, (diff.numel(), diff[:8].tolist())
+    net = FusedC4Net.from_module(model)
+    with torch.no_grad():
+        for q in model.parameters():
+            q.add_(0.01 * torch.randn_like(q))
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.add_(0.05)
+                m.running_var.mul_(1.3)
+    net.load_module(model)
+    assert torch.equal(net.blob, _pack_c4_blob_torch(model))
