@@ -47,6 +47,7 @@ SIGNATURES = {
     'az_engine_create': (C.c_int, [C.POINTER(EngineConfig), C.POINTER(_P)]),
     'az_engine_destroy': (C.c_int, [_P]),
     'az_reset_games': (C.c_int, [_P, _P]),
+    'az_abandon_games': (C.c_int, [_P, _P]),
     'az_set_puct_lut': (C.c_int, [_P, _P, C.c_int32]),
     'az_set_model_version': (C.c_int, [_P, C.c_int32]),
     'az_begin_move': (C.c_int, [_P, _P, _P, _P]),

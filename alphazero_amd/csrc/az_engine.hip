@@ -362,6 +362,20 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_reset(Dev E) {
     }
 }
 
+// every game in progress is given up and its slot starts the game that would have come next (the uid moves on, so no
+// random stream is used twice); statistics, error bits and the record ring stay as they are
+template <class GM>
+__global__ void __launch_bounds__(BLOCK_THREADS) k_abandon(Dev E) {
+    WAVE_PROLOGUE
+    if (lane == 0) {
+        s->nx = 0; s->pv = 0; s->nm = 0;
+        s->uid += E.uid_stride;
+        s->root = AZ_NO_NODE; s->alloc = 0;
+        s->leaf_kind = AZ_LEAF_NONE; s->leaf_depth = 0; s->leaf_nm = 0; s->leaf_nx = 0; s->leaf_pv = 0;
+        s->move_sims = 0; s->first_version = E.version;
+    }
+}
+
 // mcts.py:114-117.  UNIFORM: expand with 1/n in place and add the noise here.
 template <class GM, bool UNIFORM>
 __global__ void __launch_bounds__(BLOCK_THREADS)
@@ -1814,6 +1828,14 @@ int az_reset_games(az_engine* e, void* stream) {
     e->err_flags = 0;
     // the reset touches slots only, whatever the game
     hipLaunchKernelGGL((k_reset<GameC4>), wave_grid(e->d.G), dim3(BLOCK_THREADS), 0, st, e->d);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int az_abandon_games(az_engine* e, void* stream) {
+    if (!e) return az_fail("null engine");
+    ENGINE_SCOPE(e);
+    hipLaunchKernelGGL((k_abandon<GameC4>), wave_grid(e->d.G), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, e->d);
     LAUNCH_CHECK();
     return 0;
 }

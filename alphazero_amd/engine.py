@@ -99,6 +99,10 @@ class SelfPlayEngine:
     def reset_games(self):
         check(self.lib.az_reset_games(self.h, self._stream()))
 
+    def abandon_games(self):
+        """Give up every game in progress; the slots start their next games (new uids) under the current model version."""
+        check(self.lib.az_abandon_games(self.h, self._stream()))
+
     def enable_eval_cache(self, log2_entries):
         """Device table of 2**log2_entries evaluator outputs keyed by (position, model version); 0
         turns it off.  sim_step then answers repeated leaves itself (LEAF_CACHED) and writes their rows

@@ -11,12 +11,16 @@ they are.  Collaborators are duck-typed exactly as in the reference:
 `config.Game()`, `config.Model()`, `config.selfplay[...]`.
 
 Where this differs from the reference, because game slots outlive a call:
-  * a game can span several model versions (weights are refreshed once per `play_game()` /
+  * by default a game can span several model versions (weights are refreshed once per `play_game()` /
     `play_moves()` call, games finish whenever they finish), and with `reuse_search_tree` its tree keeps
     the priors and values of the weights that expanded each node -- including the uniform prior of
     version 0 across the switch to the first real weights.  The reference plays a whole game with one
     version (selfplay.py:18,41).  `dataset.add_game(game, v)` gets the version current when the game
     ENDED; the record also carries the version current when it STARTED (`first_model_version`).
+    `one_version_per_game=True` gives the reference's rule instead: when `refresh_model()` finds new weights the
+    games in progress are given up (az_abandon_games) and `play_game()` plays a whole generation -- until every
+    slot has finished the game it started under these weights -- so no game and no search tree ever sees two
+    versions, at the price of the games that were under way when the weights changed.
   * pool exhaustion and record-ring overflow cannot happen in the reference; here `collect_finished*`
     raises AzError as soon as the engine reports either.
 """
@@ -38,7 +42,8 @@ def record_to_game(game_cls, rec):
 
 class SelfPlayWorker:
     def __init__(self, config, model_server, dataset, device, num_games=1024, seed=0,
-                 rank=0, world_size=1, evaluator=None, eval_cache_log2=0, net_precision='bf16'):
+                 rank=0, world_size=1, evaluator=None, eval_cache_log2=0, net_precision='bf16',
+                 one_version_per_game=False):
         # net_precision (Connect Four networks with up to 32 trunk channels): 'bf16' = the bf16 MFMA network, the
         # fast path; 'fp32' = the network at the reference's own precision (alphazero/mcts.py:94-107 evaluates in
         # fp32) on fp16-pair operands, outputs within 1e-5 of the torch module, about a third of the bf16 rate
@@ -98,8 +103,11 @@ class SelfPlayWorker:
         if self._fused is not None and not self._fused_move and self.num_games > 32768:
             raise ValueError('the HIP network kernels take at most 32768 leaves per call: num_games <= 32768')
         self._version = 0
+        self._one_version = bool(one_version_per_game)
+        self._first_uid, self._uid_stride = rank * self.num_games, world_size * self.num_games
         self.positions = 0
         self.games_finished = 0
+        self.games_abandoned = 0
 
     # ---- one move for every game slot -----------------------------------------------
     def _eval(self, bb, info):
@@ -139,11 +147,13 @@ class SelfPlayWorker:
                 ('finished games were dropped, the record ring was full (collect more often); ' if flags & 2 else '') +
                 ('a launch of the one-launch-per-move kernel was abandoned by its watchdog' if flags & 16 else ''))
 
-    def collect_finished(self):
+    def collect_finished(self, slots_done=None):
         recs = self.engine.drain_finished()
         self._check_engine()
         for r in recs:
             self._dataset.add_game(record_to_game(self._game_cls, r), int(r.model_version))
+            if slots_done is not None:
+                slots_done[(int(r.uid) - self._first_uid) % self._uid_stride] = True
         self.games_finished += len(recs)
         return len(recs)
 
@@ -185,15 +195,33 @@ class SelfPlayWorker:
 
     def refresh_model(self):
         """selfplay.py:16-22: pull the latest weights; version 0 means 'no model yet'."""
+        before = self._version
         self._version = int(self._model_server.latest(self._model))
         self.engine.set_model_version(self._version)
         if self._fused is not None and self._version > 0:
             self._fused.load_module(self._model)
+        if self._one_version and self._version != before:
+            # selfplay.py:16-22,41: a game is played from start to end with the weights that were the latest when it
+            # began; the games under way belong to the old weights
+            if self.positions:
+                self.collect_finished()
+                self.engine.abandon_games()
+                self.games_abandoned += self.num_games
+            else:
+                self.engine.reset_games()              # nothing played yet: the empty games just take the version
         return self._version
 
     def play_game(self):
         version = self.refresh_model()
         uniform = version <= 0 and self._evaluator is None
+        if self._one_version:
+            # a generation: every slot finishes the game it has under way (all of them under `version`; a slot that
+            # finishes early starts another one under the same weights, which is collected if it ends in time)
+            done = np.zeros(self.num_games, dtype=bool)
+            while not done.all():
+                self.play_move(uniform)
+                self.collect_finished(done)
+            return version
         finished = 0
         while finished == 0:
             self.play_move(uniform)

@@ -103,6 +103,10 @@ int  az_engine_create(const az_engine_config* cfg, az_engine** out);
 int  az_engine_destroy(az_engine* e);
 /* selfplay.py:13-14: every slot gets an empty game and an un-expanded root  */
 int  az_reset_games(az_engine* e, void* stream);
+/* Every game in progress is given up (no record) and its slot starts the game that would have come next, with an
+ * un-expanded root, under the model version current now.  For callers that want the reference's rule that a game is
+ * played from start to end with one set of weights (selfplay.py:16-22,41): call it when new weights arrive.        */
+int  az_abandon_games(az_engine* e, void* stream);
 /* PUCT table, HOST pointer, n rows of {Cs, sqrt(Ns)} indexed by Ns = sum N
  * (mcts.py:55-57 evaluated by the host's numpy, so the transcendental is the
  * reference's own).  Synchronous.  az_engine_create installs a table from the
