@@ -430,3 +430,33 @@ def test_one_version_per_game_follows_the_reference_rule():
     w, seen, _ = run(False, 14)
     assert any(first != last for _, first, last in seen)
     assert w.games_abandoned == 0
+
+
+def test_worker_on_two_streams_plays_the_games_of_the_one_stream_worker():
+    """SelfPlayWorker(streams=2): the games split over two engines on two HIP streams (one half's search step runs
+    under the other half's network evaluation).  The halves own the uids of the one-engine worker, so the same games
+    come out, visit counts included; refresh, collection and the error check go over both engines."""
+    from alphazero_amd.models import AlphaZeroC4
+    from alphazero_amd.selfplay import SelfPlayWorker
+    model = {'module': 'alphazero.games.connectfour', 'name': 'AlphaZeroC4',
+             'kwargs': {'num_blocks': 2, 'channels_per_block': 128}}
+    cfg = _config({'module': 'alphazero.games.connectfour', 'name': 'ConnectFour'}, model, S=20)
+    torch.manual_seed(0)
+    state = AlphaZeroC4(2, 128).state_dict()
+    played = []
+    for streams in (1, 2):
+        ds, srv = _Dataset(), _Server(3, state)
+        w = SelfPlayWorker(cfg, srv, ds, 'cuda', num_games=48, seed=9, streams=streams)
+        assert len(w.engines) == streams and not w._fused_move
+        for _ in range(45):
+            w.play_game()
+        _check_games(ds, orc.C4, 20, True)
+        assert all(e.stats()['errors'] == 0 for e in w.engines)
+        played.append(sorted((tuple(g.history), tuple(int(x) for n in g.search_statistics for x in n)) for g, _ in ds.games))
+        for e in w.engines:
+            e.close()
+    assert len(played[0]) >= 48 and played[0] == played[1]
+    with pytest.raises(ValueError):
+        SelfPlayWorker(_config({'module': 'alphazero.games.connectfour', 'name': 'ConnectFour'},
+                               {'module': 'alphazero.games.connectfour', 'name': 'AlphaZeroC4',
+                                'kwargs': {'num_blocks': 2, 'channels_per_block': 16}}, S=20), srv, ds, 'cuda', num_games=48, streams=2)
