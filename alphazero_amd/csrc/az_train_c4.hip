@@ -155,7 +155,7 @@ k_train_head_fc_fwd(const float* __restrict__ x, const float* __restrict__ zh, c
     __shared__ int height[8];
     __shared__ double tot[64], scratch[512];
     head_fc_fwd_step(x, zh, stat_h, stat_h_keep, gp, btp, gv, btv, wpf, bpf, w1, b1, w2, b2, hplanes, h1, logits7, vhat, boards, eps,
-                     ChainExchange{part_in, nullptr, boards}, hp, cl, height, red, w1_l, wpf_l, tot, scratch);
+                     ChainExchange{part_in, nullptr, boards}, hp, cl, height, red, w1_l, wpf_l, false, tot, scratch);
 }
 
 __global__ void __launch_bounds__(TT)
@@ -294,7 +294,14 @@ __device__ __forceinline__ bool pass_steps(const PassArgs& A, float* lds, double
         ++p;
         __syncthreads();
     }
+    int* height = reinterpret_cast<int*>(small + 320);
+    float* w1_l = lds + CONV_LDS_WL;                   // [256][42]: the conv weights' and the dZ tile's place
+    float* wpf_l = lds + CONV_LDS_PBUF;                // [42][84]
     {
+        // the fully connected layers' weights go to LDS here, one exchange ahead of their use: the 1x1 convs need
+        // none of that space
+        stage_floats(w1_l, net.val_fc1_w, 256 * CELLS, tid);
+        stage_floats(wpf_l, net.pol_fc_w, CELLS * 84, tid);
         bool bad;
         if (nb == 0)
             bad = head_conv_fwd_step<false>(Zl(0), bn0, nof, Xk(0), net.pol_conv_w, net.pol_conv_b, net.val_conv_w, W + w.zh, B, eps,
@@ -308,12 +315,9 @@ __device__ __forceinline__ bool pass_steps(const PassArgs& A, float* lds, double
         ++p;
         __syncthreads();
     }
-    int* height = reinterpret_cast<int*>(small + 320);
-    float* w1_l = lds + CONV_LDS_WL;                   // [256][42]: the conv weights' and the dZ tile's place
-    float* wpf_l = lds + CONV_LDS_PBUF;                // [42][84]
     if (head_fc_fwd_step(A.x, W + w.zh, stat_h, W + w.stat_h, net.pol_bn.weight, net.pol_bn.bias, net.val_bn.weight, net.val_bn.bias,
                          net.pol_fc_w, net.pol_fc_b, net.val_fc1_w, net.val_fc1_b, net.val_fc2_w, net.val_fc2_b, W + w.hplanes,
-                         W + w.h1, W + w.logits7, W + w.vhat, B, eps, EX(p), small + 128, small + 256, height, red, w1_l, wpf_l, tot,
+                         W + w.h1, W + w.logits7, W + w.vhat, B, eps, EX(p), small + 128, small + 256, height, red, w1_l, wpf_l, true, tot,
                          scratch))
         return true;
     __syncthreads();

@@ -478,14 +478,16 @@ __device__ __forceinline__ bool head_fc_fwd_step(const float* x, const float* zh
                                                  float* hplanes /* [board][128]: 84 policy, 42 value */, float* h1 /* [board][256] */,
                                                  float* logits7, float* vhat, int boards, float eps, const EX& ex, float* hp /* LDS [128] */,
                                                  float* cl /* LDS [42] */, int* height /* LDS [8] */, float* red /* LDS [256] */,
-                                                 float* w1_l /* LDS [256][42] */, float* wpf_l /* LDS [42][84] */, double* tot,
-                                                 double* scratch) {
+                                                 float* w1_l /* LDS [256][42] */, float* wpf_l /* LDS [42][84] */, bool staged,
+                                                 double* tot, double* scratch) {
     const int b = blockIdx.x, tid = step_tid();
     const bool on = tid < TT;
     // the fully connected layers' weights into LDS while the batch sums are on their way (a thread of the layers below
-    // reads one row of a matrix: from global memory that is a chain of uncoalesced loads)
-    stage_floats(w1_l, w1, 256 * CELLS, tid);
-    stage_floats(wpf_l, wpf, CELLS * 84, tid);
+    // reads one row of a matrix: from global memory that is a chain of uncoalesced loads); staged: already there
+    if (!staged) {
+        stage_floats(w1_l, w1, 256 * CELLS, tid);
+        stage_floats(wpf_l, wpf, CELLS * 84, tid);
+    }
     if (ex.template gather<TT / 64>(tot, scratch)) return true;
     stats_from_totals(tot, 3, (long)boards * CELLS, eps, stat_h, stat_h_keep);
     if (tid < 3 * CELLS) {
