@@ -100,6 +100,7 @@ SIGNATURES = {
     'az_c4_train_workspace_bytes': (C.c_long, [C.c_int32, C.c_int32]),
     'az_c4_train_fwd_bwd': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P, _P]),
     'az_c4net_pack_bf16': (C.c_int, [_P, C.c_int32, C.c_double, _P, _P]),
+    'az_c4net_pack_hx': (C.c_int, [_P, C.c_int32, C.c_double, _P, _P, _P]),
     'az_c4_train_fwd_bwd_chain': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P, _P]),
     'az_c4_train_one_launch_max_batch': (C.c_int, [C.c_int32, _P]),
     'az_tttnet_f32_blob_floats': (C.c_int, [C.c_int32]),

@@ -12,6 +12,7 @@
 // bias is the accumulator's initial value.  The fully connected heads run once per round for
 // the whole workgroup on v_mfma_f32_32x32x16_bf16 from small planes in LDS.
 #include "az_net_dev.h"
+#include "az_pack_dev.h"
 #include "az_host.h"
 
 __global__ void __launch_bounds__(NTHREADS, 2)
@@ -155,13 +156,8 @@ k_c4net_bf16(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* _
 }
 
 // ---- the module's parameters -> the packed weights, in one launch ---------------------------------------------
-// (the statement of this layout in tensor operations is net.py:_pack_c4_blob_torch; same bytes)
-// Eval-mode batch-norm folded into the conv in double, as the packing always did: s = gamma / sqrt(var + eps),
-// w' = w * s, b' = beta - mean * s (+ conv bias * s); then double -> float -> bf16, round to nearest even both times.
-struct FoldBn { const float* gamma; const float* beta; const float* mean; const float* var; };
-__device__ __forceinline__ double fold_scale(const FoldBn& bn, int c, double eps) {
-    return (double)bn.gamma[c] / sqrt((double)bn.var[c] + eps);
-}
+// (the statement of this layout in tensor operations is net.py:_pack_c4_blob_torch; same bytes): batch-norm folded in
+// double (az_pack_dev.h), then double -> float -> bf16, round to nearest even both times.
 __device__ __forceinline__ uint16_t to_bf16(double x) {
     const float f = (float)x;
     uint32_t u = __float_as_uint(f);
@@ -169,22 +165,9 @@ __device__ __forceinline__ uint16_t to_bf16(double x) {
     u += 0x7FFFu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
 }
-struct PackArgs {
-    int channels, num_blocks;
-    double eps;
-    const float* stem_w; FoldBn stem_bn;
-    const float* c1_w; FoldBn bn1;
-    const float* c2_w; FoldBn bn2;
-    const float* pol_conv_w; const float* pol_conv_b; FoldBn pol_bn;
-    const float* val_conv_w; FoldBn val_bn;
-    const float* val_fc1_w; const float* val_fc1_b; const float* val_fc2_w; const float* val_fc2_b;
-    const float* pol_fc_w; const float* pol_fc_b;
-};
-// output channel computed by row r of MFMA half h in the trunk (the MFMA result lands in the lanes' own B-fragment layout)
-__device__ __forceinline__ int half_row(int h, int r) { return 8 * (r / 4) + 4 * h + r % 4; }
 
 __global__ void __launch_bounds__(256) k_pack_c4_bf16(const PackArgs a, uint8_t* __restrict__ blob) {
-    const int e = blockIdx.x * 256 + threadIdx.x, C = a.channels;
+    const int e = blockIdx.x * 256 + threadIdx.x;
     const int nbf = OFF_BIAS / 2;
     if (e < nbf) {
         // one bf16 element; inside a 16x16x32 fragment [64 lanes][8]: element j of lane l is M[row = l & 15][k = 8 (l >> 4) + j],
@@ -192,27 +175,10 @@ __global__ void __launch_bounds__(256) k_pack_c4_bf16(const PackArgs a, uint8_t*
         const int byte = 2 * e, l = (e >> 3) & 63, j = e & 7;
         double v = 0.0;
         if (byte < OFF_HF) {
-            // trunk fragments [.. ][2 halves][64][8]: stem, nine taps of each conv, identity
-            const int frag = e >> 10, h = (e >> 9) & 1;
-            const int co = half_row(h, l & 15), k = 8 * (l >> 4) + j;
-            if (frag == 0) {
-                if (co < C && k < 27 && k % 9 < 6) {             // k = 9 kx + 3 plane + ky: 18 of the 32 are used
-                    const int kx = k / 9, plane = (k % 9) / 3, ky = k % 3;
-                    v = (double)a.stem_w[((co * 2 + plane) * 3 + ky) * 3 + kx] * fold_scale(a.stem_bn, co, a.eps);
-                }
-            } else if (frag <= 18) {
-                const int conv = (frag - 1) / 9, tap = (frag - 1) % 9;
-                if (a.num_blocks > 0 && co < C && k < C)
-                    v = (double)(conv ? a.c2_w : a.c1_w)[(co * C + k) * 9 + tap] * fold_scale(conv ? a.bn2 : a.bn1, co, a.eps);
-            } else {
-                v = co == k ? 1.0 : 0.0;
-            }
+            // trunk fragments [..][2 halves][64][8]: stem, nine taps of each conv, identity
+            v = trunk_weight(a, e >> 10, half_row((e >> 9) & 1, l & 15), 8 * (l >> 4) + j);
         } else if (byte < OFF_F1) {
-            const int row = l & 15, k = 8 * (l >> 4) + j;
-            if (k < C) {
-                if (row < 2) v = (double)a.pol_conv_w[row * C + k] * fold_scale(a.pol_bn, row, a.eps);
-                else if (row == 2) v = (double)a.val_conv_w[k] * fold_scale(a.val_bn, 0, a.eps);
-            }
+            v = head_conv_weight(a, l & 15, 8 * (l >> 4) + j);
         } else if (byte < OFF_PF) {
             const int q = e - OFF_F1 / 2, tile = q / 1536, s = (q / 512) % 3;
             const int row = 32 * tile + (l & 31), k = 16 * s + 8 * (l >> 5) + j;
@@ -227,30 +193,12 @@ __global__ void __launch_bounds__(256) k_pack_c4_bf16(const PackArgs a, uint8_t*
     }
     const int f = e - nbf;
     if (f >= (BLOB_BYTES - OFF_BIAS) / 4) return;
-    double v = 0.0;
-    if (f < 96) {
-        const int layer = f / 32, c = f % 32;
-        if (c < C && (layer == 0 || a.num_blocks > 0)) {
-            const FoldBn& bn = layer == 0 ? a.stem_bn : layer == 1 ? a.bn1 : a.bn2;
-            v = (double)bn.beta[c] - (double)bn.mean[c] * fold_scale(bn, c, a.eps);
-        }
-    } else if (f < 98) {
-        const int c = f - 96;
-        const double s = fold_scale(a.pol_bn, c, a.eps);
-        v = ((double)a.pol_bn.beta[c] - (double)a.pol_bn.mean[c] * s) + (double)a.pol_conv_b[c] * s;
-    } else if (f == 98) {
-        v = (double)a.val_bn.beta[0] - (double)a.val_bn.mean[0] * fold_scale(a.val_bn, 0, a.eps);
-    } else if (f < 100) {
-        v = 0.0;
-    } else if (f < 100 + 64) {
-        v = f - 100 < 42 ? (double)a.pol_fc_b[f - 100] : 0.0;
-    } else if (f < 100 + 64 + 256) {
-        v = (double)a.val_fc1_b[f - 164];
-    } else if (f < 100 + 64 + 512) {
-        v = (double)a.val_fc2_w[f - 420];
-    } else {
-        v = f == 676 ? (double)a.val_fc2_b[0] : 0.0;
-    }
+    double v;
+    if (f < 100) v = folded_bias(a, f);
+    else if (f < 100 + 64) v = f - 100 < 42 ? (double)a.pol_fc_b[f - 100] : 0.0;
+    else if (f < 100 + 64 + 256) v = (double)a.val_fc1_b[f - 164];
+    else if (f < 100 + 64 + 512) v = (double)a.val_fc2_w[f - 420];
+    else v = f == 676 ? (double)a.val_fc2_b[0] : 0.0;
     reinterpret_cast<float*>(blob + OFF_BIAS)[f] = (float)v;
 }
 
@@ -261,16 +209,7 @@ int az_c4net_blob_bytes(void) { return BLOB_BYTES; }
 int az_c4net_pack_bf16(const az_c4_train_net* net, int32_t channels, double bn_eps, uint8_t* blob, void* stream) {
     if (!net || !blob || channels < 1 || channels > 32 || net->num_blocks < 0)
         return az_fail("az_c4net_pack_bf16: null pointer, or not 1..32 trunk channels");
-    auto bn = [](const az_bn& b) { return FoldBn{b.weight, b.bias, b.running_mean, b.running_var}; };
-    PackArgs a;
-    a.channels = channels; a.num_blocks = net->num_blocks; a.eps = bn_eps;
-    a.stem_w = net->stem_w; a.stem_bn = bn(net->stem_bn);
-    a.c1_w = net->c1_w; a.bn1 = bn(net->bn1);
-    a.c2_w = net->c2_w; a.bn2 = bn(net->bn2);
-    a.pol_conv_w = net->pol_conv_w; a.pol_conv_b = net->pol_conv_b; a.pol_bn = bn(net->pol_bn);
-    a.val_conv_w = net->val_conv_w; a.val_bn = bn(net->val_bn);
-    a.val_fc1_w = net->val_fc1_w; a.val_fc1_b = net->val_fc1_b; a.val_fc2_w = net->val_fc2_w; a.val_fc2_b = net->val_fc2_b;
-    a.pol_fc_w = net->pol_fc_w; a.pol_fc_b = net->pol_fc_b;
+    const PackArgs a = make_pack_args(net, channels, bn_eps);
     const int n = OFF_BIAS / 2 + (BLOB_BYTES - OFF_BIAS) / 4;
     hipLaunchKernelGGL(k_pack_c4_bf16, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, blob);
     AZ_LAUNCH_CHECK("k_pack_c4_bf16");

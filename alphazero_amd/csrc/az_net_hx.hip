@@ -8,6 +8,7 @@
 // time through trunk and heads on its own; the waves of a launch share nothing but the weights in LDS, so a
 // leaf's (p, v) do not depend on the batch it is evaluated in.
 #include "az_net_hx_dev.h"
+#include "az_pack_dev.h"
 #include "az_host.h"
 
 #define HXK_SBIAS HX_W_BYTES                         // LDS: float[128] biases
@@ -41,9 +42,69 @@ k_c4net_hx(const uint8_t* __restrict__ blob, int num_blocks, const uint64_t* __r
     }
 }
 
+// ---- the module's parameters -> the packed weights of the fp16-pair kernels, in one launch --------------------
+// (the statement of this layout in tensor operations is net.py:_pack_c4_blob_hx_torch; same bytes): batch-norm folded
+// in double, rounded once to float, then split: h = fp16(w), l = fp16((w - h) * 2048).  A weight beyond the fp16
+// range sets *range_error.
+#define HX_SPLIT_SCALE 2048.0f
+__global__ void __launch_bounds__(256) k_pack_c4_hx(const PackArgs a, uint8_t* __restrict__ blob, int* __restrict__ range_error) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int nh = HX_W_BYTES / 2;
+    if (e < nh) {
+        // one fp16 element of a 16x16x32 fragment [64 lanes][8]: element j of lane l is M[row = l & 15][k = 8 (l >> 4) + j]
+        const int byte = 2 * e, l = (e >> 3) & 63, j = e & 7, k = 8 * (l >> 4) + j;
+        double v;
+        int low;                                           // 0: the leading half h, 1: the following half l
+        if (byte < HX_OFF_ID) {
+            // stem and conv taps: [fragment][2 channel halves][h, l][64][8]
+            low = (e >> 9) & 1;
+            v = trunk_weight(a, e >> 11, half_row((e >> 10) & 1, l & 15), k);
+        } else if (byte < HX_OFF_HF) {
+            low = 0;                                       // the identity is exact: [2 channel halves][64][8]
+            v = trunk_weight(a, 19, half_row(((e - HX_OFF_ID / 2) >> 9) & 1, l & 15), k);
+        } else {
+            low = ((e - HX_OFF_HF / 2) >> 9) & 1;          // 1x1 heads: [h, l][64][8]
+            v = head_conv_weight(a, l & 15, k);
+        }
+        const float w = (float)v;
+        if (!(fabsf(w) < 6.0e4f)) *range_error = 1;
+        const _Float16 h = (_Float16)w;
+        const _Float16 out = low ? (_Float16)((w - (float)h) * HX_SPLIT_SCALE) : h;
+        reinterpret_cast<_Float16*>(blob)[e] = out;
+        return;
+    }
+    const int f = e - nh;
+    if (f >= (HX_BLOB_BYTES - HX_OFF_BIAS) / 4) return;
+    double v;
+    if (f < 99) v = folded_bias(a, f);
+    else if (f == 99) v = (double)a.val_fc2_b[0];
+    else if (f < 100 + 64) v = f - 100 < 42 ? (double)a.pol_fc_b[f - 100] : 0.0;
+    else if (f < 100 + 64 + 256) v = (double)a.val_fc1_b[f - 164];
+    else if (f < 100 + 64 + 512) v = (double)a.val_fc2_w[f - 420];
+    else if (f < 676 + 42 * 256) {
+        // [cell][lane][u] = W1[4 lane + u][cell]
+        const int q = f - 676, cell = q / 256, unit = q % 256;
+        v = (double)a.val_fc1_w[unit * 42 + cell];
+    } else {
+        v = (double)a.pol_fc_w[f - 676 - 42 * 256];
+    }
+    reinterpret_cast<float*>(blob + HX_OFF_BIAS)[f] = (float)v;
+}
+
 extern "C" {
 
 int az_c4net_hx_blob_bytes(void) { return HX_BLOB_BYTES; }
+
+int az_c4net_pack_hx(const az_c4_train_net* net, int32_t channels, double bn_eps, uint8_t* blob, int32_t* range_error_dev,
+                     void* stream) {
+    if (!net || !blob || !range_error_dev || channels < 1 || channels > 32 || net->num_blocks < 0)
+        return az_fail("az_c4net_pack_hx: null pointer, or not 1..32 trunk channels");
+    const PackArgs a = make_pack_args(net, channels, bn_eps);
+    const int n = HX_W_BYTES / 2 + (HX_BLOB_BYTES - HX_OFF_BIAS) / 4;
+    hipLaunchKernelGGL(k_pack_c4_hx, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, blob, (int*)range_error_dev);
+    AZ_LAUNCH_CHECK("k_pack_c4_hx");
+    return 0;
+}
 
 int az_c4net_hx_forward(const uint8_t* blob, int32_t num_blocks, const uint64_t* leaf_bb, const int32_t* leaf_info,
                         int32_t n, float* p, float* v, void* stream) {

@@ -325,9 +325,42 @@ def _trunk_frags_hx(w32):
     return _frags16_hx(w32[..., rows, :])
 
 
-def pack_c4_blob_hx(model):
+def pack_c4_blob_hx(model, out=None, range_error=None):
     """AlphaZeroC4 module -> uint8 tensor in the layout of csrc/az_net_hx_dev.h (BN folded in float64, weights
-    rounded once to float32, trunk weights then split into fp16 pairs)."""
+    rounded once to float32, trunk weights then split into fp16 pairs); into `out` when given.  On a GPU it is one
+    launch (az_c4net_pack_hx); range_error = a device int32[1] that the launch sets when a folded weight does not fit
+    fp16 (without it the call waits for the launch and raises, like the tensor statement _pack_c4_blob_hx_torch, which
+    a module on the CPU goes through and which gives the same bytes)."""
+    dev = model._cbr[0].weight.device
+    if dev.type != 'cuda' or any(t.dtype != torch.float32 or not t.is_contiguous() for t in model.parameters()):
+        blob = _pack_c4_blob_hx_torch(model)
+        if out is not None:
+            out.copy_(blob)
+            return out
+        return blob
+    C_ = model.block_channels
+    if C_ > CMAX or tuple(model.shape_in) != (2, 6, 7):
+        raise ValueError('fp16-pair kernel: Connect Four nets with up to 32 trunk channels')
+    from .train_c4 import param_struct
+    lib = _lib.load()
+    nbytes = lib.az_c4net_hx_blob_bytes()
+    if out is None:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    assert out.is_contiguous() and out.dtype == torch.uint8 and out.numel() == nbytes and out.device == dev
+    wait = range_error is None
+    if wait:
+        range_error = torch.zeros(1, dtype=torch.int32, device=dev)
+    net = param_struct(model, [])
+    eps = float(model._cbr[1].eps)
+    assert all(float(m.eps) == eps for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d))
+    _launch(_device(dev), lambda st: lib.az_c4net_pack_hx(C.byref(net), C_, C.c_double(eps), ptr(out), ptr(range_error), st))
+    if wait and int(range_error.item()):
+        raise ValueError('fp16-pair kernel: a folded weight lies beyond the fp16 range')
+    return out
+
+
+def _pack_c4_blob_hx_torch(model):
+    """The packed layout of csrc/az_net_hx_dev.h stated in tensor operations."""
     C_ = model.block_channels
     if C_ > CMAX or tuple(model.shape_in) != (2, 6, 7):
         raise ValueError('fp16-pair kernel: Connect Four nets with up to 32 trunk channels')
@@ -389,10 +422,19 @@ class FusedC4NetHX:
         self.blob.copy_(blob)
         assert self.blob.data_ptr() % 16 == 0
         self._p = self._v = None
+        self.range_error = torch.zeros(1, dtype=torch.int32, device=self.device)
 
-    def load_module(self, model):
-        self.blob.copy_(pack_c4_blob_hx(model))
+    def load_module(self, model, check=False):
+        """Refresh the packed weights.  A folded weight beyond the fp16 range sets self.range_error (device int32[1],
+        sticky) instead of raising, so that a training loop can hand weights over after every step without waiting
+        for the device; check=True waits and raises."""
+        if next(model.parameters()).device == self.blob.device:
+            pack_c4_blob_hx(model, out=self.blob, range_error=self.range_error)
+        else:
+            self.blob.copy_(pack_c4_blob_hx(model))
         self.num_blocks = model.num_blocks
+        if check and int(self.range_error.item()):
+            raise ValueError('fp16-pair kernel: a folded weight lies beyond the fp16 range')
 
     def __call__(self, leaf_bb, leaf_info=None):
         n = leaf_bb.shape[0]

@@ -345,6 +345,10 @@ int  az_c4net_f32_forward(const float* blob, int32_t num_blocks, const uint64_t*
  * DEVICE buffer of az_c4net_hx_blob_bytes() bytes (alphazero_amd/net.py pack_c4_blob_hx); leaf_info as for
  * az_c4net_bf16_forward (NULL = every leaf).  Activations saturate at 65504.  Replaces the same reference lines. */
 int  az_c4net_hx_blob_bytes(void);
+/* az_c4net_pack_bf16 for this layout (the bytes of alphazero_amd.net._pack_c4_blob_hx_torch).  A folded weight beyond
+ * the fp16 range (|w| >= 6e4) sets range_error_dev[0] (DEVICE int32, never cleared here) to 1.                    */
+int  az_c4net_pack_hx(const az_c4_train_net* net, int32_t channels, double bn_eps, uint8_t* blob,
+                      int32_t* range_error_dev, void* stream);
 int  az_c4net_hx_forward(const uint8_t* blob, int32_t num_blocks, const uint64_t* leaf_bb,
                          const int32_t* leaf_info, int32_t n, float* p, float* v, void* stream);
 

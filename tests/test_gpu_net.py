@@ -483,3 +483,37 @@ def test_packing_kernel_writes_the_bytes_of_the_tensor_statement(blocks, channel
                 m.running_var.mul_(1.3)
     net.load_module(model)
     assert torch.equal(net.blob, _pack_c4_blob_torch(model))
+
+
+@pytest.mark.parametrize('blocks,channels', [(6, 32), (2, 16), (0, 32), (3, 8)])
+def test_fp16_pair_packing_kernel_writes_the_bytes_of_the_tensor_statement(blocks, channels):
+    """az_c4net_pack_hx against net._pack_c4_blob_hx_torch: equal byte for byte; a weight beyond the fp16 range is
+    reported (raised by pack_c4_blob_hx, a sticky device flag for FusedC4NetHX.load_module)."""
+    from alphazero_amd.models import AlphaZeroC4
+    from alphazero_amd.net import FusedC4NetHX, _pack_c4_blob_hx_torch, pack_c4_blob_hx
+    torch.manual_seed(11 * blocks + channels)
+    model = AlphaZeroC4(blocks, channels)
+    _randomize_bn(model, blocks + channels + 1)
+    with torch.no_grad():
+        model._policy_head._fc.bias.uniform_(-0.1, 0.1)
+        model._value_head._fc[2].bias.uniform_(-0.1, 0.1)
+        model._policy_head._cbr[0].bias.uniform_(-0.2, 0.2)
+    model = model.cuda().eval()
+    want = _pack_c4_blob_hx_torch(model)
+    got = pack_c4_blob_hx(model)
+    diff = (got != want).nonzero().reshape(-1)
+    assert got.shape == want.shape and diff.numel() == 0, (diff.numel(), diff[:8].tolist())
+    net = FusedC4NetHX(model)
+    with torch.no_grad():
+        for q in model.parameters():
+            q.add_(0.01 * torch.randn_like(q))
+    net.load_module(model, check=True)
+    assert torch.equal(net.blob, _pack_c4_blob_hx_torch(model)) and int(net.range_error) == 0
+    with torch.no_grad():
+        model._cbr[0].weight[0, 0, 0, 0] = 1.0e6
+    with pytest.raises(ValueError):
+        pack_c4_blob_hx(model)
+    net.load_module(model)
+    assert int(net.range_error) == 1
+    with pytest.raises(ValueError):
+        net.load_module(model, check=True)
