@@ -149,6 +149,10 @@ struct ResidentExchange {
     }
     __device__ __forceinline__ long long* marks() const { return detail; }
     __device__ __forceinline__ void post(float v) const {
+#ifdef PASS_TEST_STALL
+        // test builds: workgroup 1 never posts its row of the step tagged PASS_TEST_STALL, so every reader has to give up
+        if (blockIdx.x == 1 && (tag_out & 0xFFu) == PASS_TEST_STALL) return;
+#endif
         __hip_atomic_store(rows_out + (size_t)blockIdx.x * 64 + threadIdx.x, ((unsigned long long)tag_out << 32) | __float_as_uint(v),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

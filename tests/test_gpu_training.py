@@ -373,6 +373,25 @@ def test_one_launch_training_pass_equals_the_chain_of_launches(blocks, B):
                 v.add_(v.grad, alpha=-0.05)
 
 
+def test_one_launch_training_pass_gives_up_when_a_workgroup_does_not_arrive():
+    """The resident grid of the one-launch pass must drain whatever happens.  A test build of the library
+    (-DPASS_TEST_STALL=7, made by __graft_entry__.build()) lets workgroup 1 withhold its row of step 7; in a child
+    process that loads it, every reader gives up after a fraction of a second, the launch ends with out3 = {NaN, NaN,
+    inf}, a second pass does the same (the error word is cleared in between) and the chain form still works."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    variant = os.path.join(root, 'alphazero_amd', 'variants', 'pass_stall.so')
+    if not os.path.exists(variant):
+        pytest.skip('alphazero_amd/variants/pass_stall.so is not built (__graft_entry__.build() makes it)')
+    env = dict(os.environ, AZHIP_LIBRARY=variant)
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'exp_train_pass_stall.py')], env=env, capture_output=True,
+                       text=True, timeout=180)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert 'gave up cleanly twice' in r.stdout, r.stdout
+
+
 def test_training_worker_with_the_hand_written_pass_follows_the_torch_path(monkeypatch):
     """Six process_batch() calls of TrainingWorker on the shipped 6 x 32 network (config/connectfour.yaml:8-9) with
     the hand-written pass and with PyTorch's forward / backward (AZ_TRAIN_HANDWRITTEN=0) from the same seeds and
