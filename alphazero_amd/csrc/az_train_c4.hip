@@ -86,8 +86,8 @@ Ws layout(int boards, int blocks) {
 }
 }  // namespace
 
-// weights of the 3x3 convs in the orders the steps read them: wf [tap][ci][co] (forward), wb [tap][co][ci]
-// (input gradient); stem: ws [tap * 2 + plane][co].  Also clears what the pass accumulates into, and the error word
+// weights of the 3x3 convs in the orders the steps read them: wf [tap][ci][co'] (forward), wb [tap][co][ci']
+// (input gradient), the second index with its halves swapped in odd rows; stem: ws [tap * 2 + plane][co].  Also clears what the pass accumulates into, and the error word
 // of the one-launch form.
 __global__ void __launch_bounds__(TT)
 k_train_prep(const float* __restrict__ c1, const float* __restrict__ c2, const float* __restrict__ stem, float* __restrict__ wf1,
@@ -95,10 +95,13 @@ k_train_prep(const float* __restrict__ c1, const float* __restrict__ c2, const f
              float* __restrict__ bn_acc /* [3][64] */, int* __restrict__ ctl) {
     const int i = blockIdx.x * TT + threadIdx.x;
     if (i < 9 * TC * TC) {
+        // (within a row the two halves of 16 change places when the row's index is odd: the four rows that one matrix
+        // instruction's operand is read from then lie in different LDS banks, conv_mfma)
         const int tap = i / (TC * TC), ci = (i / TC) % TC, co = i % TC;
         const float a = c1[(co * TC + ci) * 9 + tap], b = c2[(co * TC + ci) * 9 + tap];
-        wf1[i] = a; wf2[i] = b;
-        wb1[(tap * TC + co) * TC + ci] = a; wb2[(tap * TC + co) * TC + ci] = b;
+        const int f = (tap * TC + ci) * TC + (co ^ ((ci & 1) * 16)), g = (tap * TC + co) * TC + (ci ^ ((co & 1) * 16));
+        wf1[f] = a; wf2[f] = b;
+        wb1[g] = a; wb2[g] = b;
     }
     if (i < 18 * TC) {
         const int tap = i / (2 * TC), plane = (i / TC) % 2, co = i % TC;

@@ -27,8 +27,6 @@
 #define EPT 3                  // elements of a board tensor [42][32] per thread of a conv step: element tid + 512 j is
                                // (cell = group + 16 j, channel = tid & 31) -- the same cells the thread computes
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 // The thread's index as a value the compiler has to take as new each time: in the one-launch pass the steps sit in
 // loops, and everything a step derives from the thread index (LDS addresses, cell numbers, masks) would otherwise be
@@ -206,34 +204,83 @@ __device__ __forceinline__ void bn_scale_shift(const float* st, const float* gam
     }
 }
 
-// The 3x3 conv of one board on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32: D[32 out][32 cells] += W[out][2 k]
-// X[2 k][cells]), by the workgroup's eight waves: wave = (cell tile: cells 0..31 / 32..63 of which 42 exist, tap
-// group: taps 0-2 / 3-4 / 5-6 / 7-8).  The forward conv (SIGN = +1, w = [tap][ci][co]) and the input gradient
-// (SIGN = -1, w = [tap][co][ci]) are the same loop.  A wave leaves its partial result in pbuf [tap group][out][PBS];
-// the caller adds the four groups up in order.  tile = [72 padded cells][TS].
+// The 3x3 conv of one board on the fp32 matrix instruction v_mfma_f32_16x16x4_f32 (D[16 out][16 cells] += W[out][4 k]
+// X[4 k][cells]): the board is three tiles of 16 cells (42 of 48 exist; 32-wide tiles would carry 64), the output two
+// halves of 16 channels.  Waves 0..5 take one (channel half, cell tile) each through taps 0..6, waves 6 and 7 the
+// taps 7 and 8 of three of those each: 56 and 48 matrix instructions per wave, 104 to 112 per SIMD.  The forward conv
+// (SIGN = +1, w = [tap][ci][co]) and the input gradient (SIGN = -1, w = [tap][co][ci]) are the same loop; in both the
+// second index has its halves of 16 swapped in odd rows (k_train_prep), which spreads the four rows of an operand
+// over the LDS banks.  A wave
+// leaves its result in pbuf [first taps / last taps][out][PBS]; the caller adds the two up.  tile = [72 padded cells][TS].
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 template <int SIGN>
 __device__ __forceinline__ void conv_mfma(const float* tile, const float* w, float* pbuf, int wave, int lane) {
-    const int col = lane & 31, h = lane >> 5, pt = wave & 1, kq = wave >> 1;
-    const int cell = pt * 32 + col;
-    const int pi = pad_index(cell < CELLS ? cell : 0);
-    const int t0 = kq == 0 ? 0 : 1 + 2 * kq, nt = kq == 0 ? 3 : 2;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int col = lane & 15, kq = lane >> 4;
+    // (a wave's matrix instructions go to independent accumulators in turn: one that waits for its predecessor's
+    // result leaves the pipe idle for more than half of the time)
+    if (wave < 6) {
+        const int ot = wave & 1, ct = wave >> 1;
+        const int cell = ct * 16 + col;
+        const int pi = pad_index(cell < CELLS ? cell : 0);
+        f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc0;
+        const float* wbase = w + kq * TC + ((ot * 16 + col) ^ ((kq & 1) * 16));
+        const float* xbase = tile + pi * TS + kq;
 #pragma unroll 1
-    for (int t = t0; t < t0 + nt; ++t) {
-        const float* xs = tile + (pi + SIGN * tap_offset(t)) * TS + h;
-        const float* ws = w + (t * TC + h) * TC + col;
+        for (int t = 0; t < 6; t += 2) {
+            const float* x0 = xbase + SIGN * tap_offset(t) * TS;
+            const float* x1 = xbase + SIGN * tap_offset(t + 1) * TS;
+            const float* w0 = wbase + t * TC * TC;
 #pragma unroll
-        for (int s2 = 0; s2 < 16; ++s2) acc = MFMA32(ws[2 * s2 * TC], xs[2 * s2], acc);
+            for (int s4 = 0; s4 < 8; ++s4) {
+                acc0 = MFMA16(w0[4 * s4 * TC], x0[4 * s4], acc0);
+                acc1 = MFMA16(w0[TC * TC + 4 * s4 * TC], x1[4 * s4], acc1);
+            }
+        }
+        {
+            const float* x0 = xbase + SIGN * tap_offset(6) * TS;
+            const float* w0 = wbase + 6 * TC * TC;
+#pragma unroll
+            for (int s4 = 0; s4 < 8; s4 += 2) {
+                acc0 = MFMA16(w0[4 * s4 * TC], x0[4 * s4], acc0);
+                acc1 = MFMA16(w0[4 * (s4 + 1) * TC], x0[4 * (s4 + 1)], acc1);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pbuf[(ot * 16 + 4 * kq + r) * PBS + cell] = acc0[r] + acc1[r];
+    } else {
+        f32x4 acc[3];
+        const float* xb[3];
+        const float* wb[3];
+        int cells[3], ots[3];
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+            const int id = (wave - 6) * 3 + n, ot = id & 1, ct = id >> 1;
+            const int cell = ct * 16 + col;
+            cells[n] = cell; ots[n] = ot;
+            xb[n] = tile + pad_index(cell < CELLS ? cell : 0) * TS + kq;
+            wb[n] = w + kq * TC + ((ot * 16 + col) ^ ((kq & 1) * 16));
+            acc[n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int t = 7; t < 9; ++t) {
+#pragma unroll
+            for (int s4 = 0; s4 < 8; ++s4) {
+#pragma unroll
+                for (int n = 0; n < 3; ++n)
+                    acc[n] = MFMA16(wb[n][(t * TC + 4 * s4) * TC], xb[n][SIGN * tap_offset(t) * TS + 4 * s4], acc[n]);
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pbuf[(TC + ots[n] * 16 + 4 * kq + r) * PBS + cells[n]] = acc[n][r];
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) pbuf[(kq * TC + (r & 3) + 8 * (r >> 2) + 4 * h) * PBS + cell] = acc[r];
 }
-// the four tap groups' partial results of (channel c, cell), added in order
+// the two partial results of (channel c, cell), added in order
 __device__ __forceinline__ float conv_total(const float* pbuf, int c, int cell) {
     const float* p = pbuf + c * PBS + cell;
-    return ((p[0] + p[TC * PBS]) + p[2 * TC * PBS]) + p[3 * TC * PBS];
+    return p[0] + p[TC * PBS];
 }
 
 // The board's share of a conv's weight gradient, dW[tap][ci][co] = sum over cells of A[cell + tap][ci] dZ[cell][co], on
@@ -241,7 +288,6 @@ __device__ __forceinline__ float conv_total(const float* pbuf, int c, int cell) 
 // four (the last two cells of the last step are zeros); the 36 units go round the eight waves (unit = wave + 8 n), so
 // a wave has five or four.  out = [tap][ci][co].  WgOld = what earlier applications of the shared block have left in
 // this wave's units (requested at the start of the step, used at its end).
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define WG_UNITS 5
 struct WgOld { f32x4 u[WG_UNITS]; };
 __device__ __forceinline__ WgOld wgrad_load_old(bool accum, const float* out, int wave, int lane) {
@@ -266,22 +312,48 @@ __device__ __forceinline__ void wgrad_mfma(const float* at, const float* dzt, fl
         pos[s4] = pad_index(cell < CELLS ? cell : 0) * TS + col;
     }
     const bool tail = kq >= 2;                         // cells 42 and 43 of the last step do not exist
+    // the wave's units side by side, step by step: five independent accumulators keep the matrix pipe busy
+    f32x4 acc[WG_UNITS];
+    const float* ap[WG_UNITS];
+    const float* dp[WG_UNITS];
+#pragma unroll
+    for (int n = 0; n < WG_UNITS; ++n) {
+        const int unit = wave + 8 * n < 36 ? wave + 8 * n : wave;          // (the idle fifth unit repeats the first)
+        const int tap = unit >> 2, ci0 = (unit & 2) * 8, co0 = (unit & 1) * 16;
+        ap[n] = at + tap_offset(tap) * TS + ci0;
+        dp[n] = dzt + co0;
+        acc[n] = old.u[n];
+    }
+    const bool five = wave + 8 * (WG_UNITS - 1) < 36;
+    // the operands of step s4 + 1 are requested before the matrix instructions of step s4 are issued (a wave issues
+    // in order: reads placed behind them would wait until the pipe has taken them all)
+    float a[2][WG_UNITS], d[2][WG_UNITS];
+#pragma unroll
+    for (int n = 0; n < WG_UNITS; ++n) { a[0][n] = ap[n][pos[0]]; d[0][n] = dp[n][pos[0]]; }
+#pragma unroll
+    for (int s4 = 0; s4 < 11; ++s4) {
+        const int cur = s4 & 1, nxt = cur ^ 1;
+        if (s4 < 10) {
+#pragma unroll
+            for (int n = 0; n < WG_UNITS; ++n) { a[nxt][n] = ap[n][pos[s4 + 1]]; d[nxt][n] = dp[n][pos[s4 + 1]]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < WG_UNITS; ++n) {
+            if (n == WG_UNITS - 1 && !five) continue;
+            float x = a[cur][n], y = d[cur][n];
+            if (s4 == 10 && tail) { x = 0.0f; y = 0.0f; }
+            acc[n] = MFMA16(x, y, acc[n]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int n = 0; n < WG_UNITS; ++n) {
         const int unit = wave + 8 * n;
         if (unit < 36) {
             const int tap = unit >> 2, ci0 = (unit & 2) * 8, co0 = (unit & 1) * 16;
-            const float* ap = at + tap_offset(tap) * TS + ci0;
-            const float* dp = dzt + co0;
-            f32x4 acc = old.u[n];
 #pragma unroll
-            for (int s4 = 0; s4 < 11; ++s4) {
-                float a = ap[pos[s4]], d = dp[pos[s4]];
-                if (s4 == 10 && tail) { a = 0.0f; d = 0.0f; }
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, d, acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) out[(tap * TC + ci0 + r4 + i) * TC + co0 + col] = acc[i];
+            for (int i = 0; i < 4; ++i) out[(tap * TC + ci0 + r4 + i) * TC + co0 + col] = acc[n][i];
         }
     }
 }
@@ -311,7 +383,7 @@ __device__ __forceinline__ void store_conv_weights(float* wl, const WRegs& x) {
 #define CONV_LDS_AT (CONV_LDS_DZT + PADCELLS * TS)         // [72][TS] A
 #define CONV_LDS_COEF (CONV_LDS_AT + PADCELLS * TS)        // 7 x [32]: sc, sh, k1, m1, m2, mean, invstd
 #define CONV_LDS_RED (CONV_LDS_COEF + 7 * TC)              // [1024]
-#define CONV_LDS_PBUF (CONV_LDS_RED + 1024)                // [4][32][PBS]
+#define CONV_LDS_PBUF (CONV_LDS_RED + 1024)                // [4][32][PBS] (the conv uses half of it, the heads the rest)
 #define CONV_LDS_FLOATS (CONV_LDS_PBUF + 4 * TC * PBS)
 
 // n floats from global memory into LDS by the whole workgroup, sixteen loads of a thread in flight
