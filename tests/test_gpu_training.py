@@ -373,6 +373,39 @@ def test_one_launch_training_pass_equals_the_chain_of_launches(blocks, B):
                 v.add_(v.grad, alpha=-0.05)
 
 
+def test_one_launch_training_pass_over_many_launches_and_the_wrap_of_its_launch_counter():
+    """The rows that the workgroups of the one-launch pass exchange are recognised by a tag made of the launch counter
+    (20 bits, kept in the workspace) and the step.  3 000 passes in a row on one workspace never give up and keep
+    giving the chain's bits; so do the passes around the counter's wrap (the counter is put just below it by hand)."""
+    import copy
+    from alphazero_amd.models import AlphaZeroC4
+    from alphazero_amd.train_c4 import C4TrainStep
+    torch.manual_seed(5)
+    B = 16
+    one = AlphaZeroC4(1, 32).cuda().train()
+    chain = copy.deepcopy(one)
+    s_one, s_chain = C4TrainStep(one), C4TrainStep(chain, chain=True)
+    rng = np.random.RandomState(1)
+    x, p, z, valid = _c4_batch(B, 3, rng)
+    want = s_chain.run(x, p, z, valid).clone()
+    grads = [q.grad.clone() for q in chain.parameters()]
+    for it in range(3000):
+        got = s_one.run(x, p, z, valid)
+        if it % 500 == 499:
+            assert torch.equal(got, want), (it, got, want)
+    # int32 {launches so far, error} sits in front of the last two areas of the workspace: 64 floats of its own, then
+    # 4 floats per board (rounded up to 64) and 512 floats of time stamps
+    ctl = s_one._ws[-4 * (512 + 64 + 64):][:8].view(torch.int32)
+    assert int(ctl[0]) == 3000 and int(ctl[1]) == 0
+    ctl[0] = 0xFFFFF - 20
+    for it in range(40):
+        got = s_one.run(x, p, z, valid)
+        assert torch.equal(got, want), (it, got, want)
+    assert int(ctl[0]) == 0xFFFFF + 20
+    for a, b in zip(one.parameters(), grads):
+        assert torch.equal(a.grad, b)
+
+
 def test_one_launch_training_pass_gives_up_when_a_workgroup_does_not_arrive():
     """The resident grid of the one-launch pass must drain whatever happens.  A test build of the library
     (-DPASS_TEST_STALL=7, made by __graft_entry__.build()) lets workgroup 1 withhold its row of step 7; in a child
