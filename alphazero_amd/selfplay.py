@@ -78,8 +78,7 @@ class SelfPlayWorker:
                 self._game_cls.AZ_GAME_ID, games, self.num_simulations,
                 exploration_depth=sp['exploration_depth'], reuse_search_tree=sp['reuse_search_tree'],
                 seed=seed, device=dev_index, first_game_uid=first_uid, uid_stride=world_size * self.num_games)
-        self.engine = make_engine(self.num_games // streams, rank * self.num_games)
-        self.engines = [self.engine]
+        self.engines = [make_engine(self.num_games // streams, rank * self.num_games)]
         self._evaluator = evaluator           # callable(leaf_bb, leaf_info) -> (p, v); None = built-in
         self._nets = [None]                   # the HIP network of each half (one half unless streams=2)
         if evaluator is None:
@@ -131,6 +130,15 @@ class SelfPlayWorker:
         self.positions = 0
         self.games_finished = 0
         self.games_abandoned = 0
+
+    @property
+    def engine(self):
+        """The engine (the first half's when the games are split over two)."""
+        return self.engines[0]
+
+    @engine.setter
+    def engine(self, eng):
+        self.engines[0] = eng
 
     @property
     def _fused(self):

@@ -481,8 +481,9 @@ def test_training_worker_with_the_hand_written_pass_follows_the_torch_path(monke
         tol = 2e-4 if i == 0 else 5e-3
         for k in snaps_a[i]:
             a, b = snaps_a[i][k], snaps_b[i][k]
-            # (+ 5e-7: the batch-norm biases start at zero and are 1e-4 after two steps)
-            assert (a - b).abs().max().item() <= tol * max(b.abs().max().item(), 1e-3) + (5e-7 if i == 0 else 2e-5), (i, k, (a - b).abs().max().item())
+            # (+ 2e-6: the batch-norm biases start at zero and are 1e-4 after two steps; the two float32 evaluations of
+            # their gradients differ by up to 1e-6 of the largest, whichever vendor kernel PyTorch picks on the box)
+            assert (a - b).abs().max().item() <= tol * max(b.abs().max().item(), 1e-3) + (2e-6 if i == 0 else 2e-5), (i, k, (a - b).abs().max().item())
 
 
 def test_window_sampling_kernel():
