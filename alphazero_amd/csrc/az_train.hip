@@ -93,13 +93,15 @@ __device__ __forceinline__ uint32_t mix32(uint64_t seed, uint64_t draw, uint32_t
 
 #define SAMPLE_MAX_WINDOW (1 << 18)          // states: one bit each in LDS
 #define SAMPLE_MAX_BATCH 2048
-__global__ void __launch_bounds__(256)
+#define SAMPLE_THREADS 1024
+__global__ void __launch_bounds__(SAMPLE_THREADS)
 k_sample_window(const float* __restrict__ wx, const float* __restrict__ wp, const float* __restrict__ wz,
                 const uint8_t* __restrict__ wvalid, int x_floats, int A, const long long* __restrict__ count_dev, int capacity,
                 unsigned long long seed, long long* __restrict__ draw_dev, int batch, float* __restrict__ x, float* __restrict__ p,
                 float* __restrict__ z, uint8_t* __restrict__ valid) {
     __shared__ uint32_t taken[SAMPLE_MAX_WINDOW / 32];
     __shared__ int pick[SAMPLE_MAX_BATCH];
+    __shared__ uint32_t first[SAMPLE_MAX_BATCH];       // every sample's first draw
     const int tid = threadIdx.x;
     const long long count = count_dev[0];
     const int n = count < capacity ? (int)count : capacity;
@@ -110,25 +112,24 @@ k_sample_window(const float* __restrict__ wx, const float* __restrict__ wp, cons
     // in parallel; only when two of them coincide (one batch in six for 128 of 50 000 states) does thread 0 go through
     // the samples in order, which is what defines the result in both cases.
     const bool distinct = batch <= n;
-    for (int i = tid; i < (n + 31) / 32; i += 256) taken[i] = 0u;
+    for (int i = tid; i < (n + 31) / 32; i += SAMPLE_THREADS) taken[i] = 0u;
     if (tid == 0) repeated = 0;
     __syncthreads();
-    for (int i = tid; i < batch; i += 256) {
+    for (int i = tid; i < batch; i += SAMPLE_THREADS) {
         const uint32_t r = (uint32_t)(((uint64_t)mix32(seed, draw, (uint32_t)i, 0) * (uint64_t)n) >> 32);
         if (distinct && ((atomicOr(&taken[r >> 5], 1u << (r & 31)) >> (r & 31)) & 1u)) repeated = 1;
+        first[i] = r;
         pick[i] = (int)(((long long)r + (count - n)) % capacity);           // the i-th oldest state sits at (count - n + i) % capacity
     }
     __syncthreads();
     if (repeated) {
-        for (int i = tid; i < (n + 31) / 32; i += 256) taken[i] = 0u;
+        for (int i = tid; i < (n + 31) / 32; i += SAMPLE_THREADS) taken[i] = 0u;
         __syncthreads();
         if (tid == 0) {
             for (int i = 0; i < batch; ++i) {
-                uint32_t r, attempt = 0;
-                for (;;) {
+                uint32_t r = first[i], attempt = 1;
+                while ((taken[r >> 5] >> (r & 31)) & 1u)
                     r = (uint32_t)(((uint64_t)mix32(seed, draw, (uint32_t)i, attempt++) * (uint64_t)n) >> 32);
-                    if (!((taken[r >> 5] >> (r & 31)) & 1u)) break;
-                }
                 taken[r >> 5] |= 1u << (r & 31);
                 pick[i] = (int)(((long long)r + (count - n)) % capacity);
             }
@@ -136,12 +137,37 @@ k_sample_window(const float* __restrict__ wx, const float* __restrict__ wp, cons
     }
     if (tid == 0) draw_dev[0] = (long long)(draw + 1);
     __syncthreads();
-    for (int i = tid; i < batch * x_floats; i += 256) x[i] = wx[(size_t)pick[i / x_floats] * x_floats + i % x_floats];
-    for (int i = tid; i < batch * A; i += 256) {
-        p[i] = wp[(size_t)pick[i / A] * A + i % A];
-        valid[i] = wvalid[(size_t)pick[i / A] * A + i % A];
+    // the gather, eight loads of a thread in flight (each is a trip to memory: one at a time they took 20 us)
+    for (int i0 = tid; i0 < batch * x_floats; i0 += 8 * SAMPLE_THREADS) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * SAMPLE_THREADS;
+            v[u] = i < batch * x_floats ? wx[(size_t)pick[i / x_floats] * x_floats + i % x_floats] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * SAMPLE_THREADS;
+            if (i < batch * x_floats) x[i] = v[u];
+        }
     }
-    for (int i = tid; i < batch; i += 256) z[i] = wz[pick[i]];
+    for (int i0 = tid; i0 < batch * A; i0 += 8 * SAMPLE_THREADS) {
+        float v[8];
+        uint8_t m[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * SAMPLE_THREADS;
+            const bool in = i < batch * A;
+            v[u] = in ? wp[(size_t)pick[i / A] * A + i % A] : 0.0f;
+            m[u] = in ? wvalid[(size_t)pick[i / A] * A + i % A] : (uint8_t)0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * SAMPLE_THREADS;
+            if (i < batch * A) { p[i] = v[u]; valid[i] = m[u]; }
+        }
+    }
+    for (int i = tid; i < batch; i += SAMPLE_THREADS) z[i] = wz[pick[i]];
 }
 
 extern "C" {
@@ -153,7 +179,7 @@ int az_sample_window(const float* wx, const float* wp, const float* wz, const ui
         return az_fail("az_sample_window: null pointer");
     if (batch <= 0 || batch > SAMPLE_MAX_BATCH || capacity <= 0 || capacity > SAMPLE_MAX_WINDOW || x_floats <= 0 || num_actions <= 0)
         return az_fail("az_sample_window: batch <= 2048 states from a window of at most 262144");
-    hipLaunchKernelGGL(k_sample_window, dim3(1), dim3(256), 0, (hipStream_t)stream, wx, wp, wz, wvalid, (int)x_floats,
+    hipLaunchKernelGGL(k_sample_window, dim3(1), dim3(SAMPLE_THREADS), 0, (hipStream_t)stream, wx, wp, wz, wvalid, (int)x_floats,
                        (int)num_actions, reinterpret_cast<const long long*>(count_dev), (int)capacity,
                        (unsigned long long)seed, reinterpret_cast<long long*>(draw_dev), (int)batch, x, p, z, valid);
     AZ_LAUNCH_CHECK("k_sample_window");

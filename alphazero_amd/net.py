@@ -137,8 +137,7 @@ def pack_c4_blob(model, out=None):
     if out is None:
         out = torch.empty(lib.az_c4net_blob_bytes(), dtype=torch.uint8, device=dev)
     assert out.is_contiguous() and out.dtype == torch.uint8 and out.numel() == lib.az_c4net_blob_bytes() and out.device == dev
-    keep = []
-    net = param_struct(model, keep)
+    net = param_struct(model)
     eps = float(model._cbr[1].eps)
     assert all(float(m.eps) == eps for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d))
     _launch(_device(dev), lambda st: lib.az_c4net_pack_bf16(C.byref(net), C_, C.c_double(eps), ptr(out), st))
@@ -350,7 +349,7 @@ def pack_c4_blob_hx(model, out=None, range_error=None):
     wait = range_error is None
     if wait:
         range_error = torch.zeros(1, dtype=torch.int32, device=dev)
-    net = param_struct(model, [])
+    net = param_struct(model)
     eps = float(model._cbr[1].eps)
     assert all(float(m.eps) == eps for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d))
     _launch(_device(dev), lambda st: lib.az_c4net_pack_hx(C.byref(net), C_, C.c_double(eps), ptr(out), ptr(range_error), st))

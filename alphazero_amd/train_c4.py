@@ -35,9 +35,9 @@ class TrainNet(C.Structure):
                 ('val_fc2_b', C.c_void_p), ('val_fc2_b_grad', C.c_void_p)]
 
 
-def param_struct(model, keep):
-    """az_c4_train_net with the module's parameters and batch-norm buffers and no gradient pointers: what
-    az_c4net_pack_bf16 reads.  Tensors made on the way (the stand-ins of a tower-less network) are appended to `keep`."""
+def param_struct(model):
+    """az_c4_train_net with the module's parameters and batch-norm buffers and no gradient pointers: what the
+    packing launches (az_c4net_pack_bf16, az_c4net_pack_hx) read.  A tower-less network leaves the block's members null."""
     m = model
 
     def bn(mod):

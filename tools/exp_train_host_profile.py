@@ -30,7 +30,7 @@ def main():
             self.version = version
     window = DeviceReplayWindow(ConnectFour, 64 * 1024, dev)
     rng = np.random.RandomState(0)
-    n = 4096
+    n = 49152                                   # (a window this large: one batch in six has two equal first draws)
     x = torch.from_numpy((rng.random_sample((n, 2, 6, 7)) < 0.2).astype(np.float32)).to(dev)
     p = torch.from_numpy(rng.dirichlet(np.ones(7), n).astype(np.float32)).to(dev)
     z = torch.from_numpy(rng.choice([-1.0, 0.0, 1.0], n).astype(np.float32)).to(dev)
