@@ -676,6 +676,10 @@ int az_c4_train_fwd_bwd(const az_c4_train_net* net, const float* x, const uint8_
     int dev = 0;
     AZ_HIPCHK(hipGetDevice(&dev));
     if (dev >= 64 || lds_set[dev].load(std::memory_order_acquire) < lds_bytes) {
+        hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+        if (st && hipStreamIsCapturing(st, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone)
+            return az_fail("az_c4_train_fwd_bwd: the first call for a device (or a deeper network) sets a kernel attribute and "
+                           "cannot be recorded in a HIP graph: call it once outside the capture");
         AZ_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_train_pass), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         if (dev < 64) lds_set[dev].store(lds_bytes, std::memory_order_release);
     }

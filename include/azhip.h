@@ -301,7 +301,8 @@ long az_c4_train_workspace_bytes(int32_t batch, int32_t num_blocks);
  * (az_c4_train_one_launch_max_batch): the weights' re-ordering and ONE launch for forward, loss, backward and the
  * batch sums, whose workgroups exchange the batch statistics among themselves; it needs all `batch` workgroups
  * resident, waits about a second for a workgroup that does not arrive and then ends with out3 = {NaN, NaN, +inf}
- * and no gradient to be used.  Larger batches, or AZ_TRAIN_CHAIN=1 in the environment: the chain below.          */
+ * and no gradient to be used.  Larger batches, or AZ_TRAIN_CHAIN=1 in the environment: the chain below.  The first
+ * call on a device sets a kernel attribute: make it outside any stream capture.                                   */
 int  az_c4_train_fwd_bwd(const az_c4_train_net* net, const float* x, const uint8_t* valid, const float* target_p,
                          const float* z, int32_t batch, void* workspace, float* out3, float* logits7_out,
                          float* vhat_out, void* stream);
