@@ -456,6 +456,23 @@ def test_worker_on_two_streams_plays_the_games_of_the_one_stream_worker():
         for e in w.engines:
             e.close()
     assert len(played[0]) >= 48 and played[0] == played[1]
+    # the tic-tac-toe network is a stepwise HIP kernel too
+    tcfg = _config({'module': 'alphazero.games.tictactoe', 'name': 'TicTacToe'},
+                   {'module': 'alphazero.models', 'name': 'AlphaZero',
+                    'kwargs': {'shape_in': [2, 3, 3], 'shape_out': [9], 'num_blocks': 3, 'block_channels': 16}}, S=24, depth=3)
+    torch.manual_seed(1)
+    tstate = tcfg.Model().state_dict()
+    played = []
+    for streams in (1, 2):
+        ds = _Dataset()
+        w = SelfPlayWorker(tcfg, _Server(2, tstate), ds, 'cuda', num_games=64, seed=4, streams=streams)
+        for _ in range(6):
+            w.play_game()
+        _check_games(ds, orc.TTT, 24, True)
+        played.append(sorted((tuple(g.history), tuple(int(x) for n in g.search_statistics for x in n)) for g, _ in ds.games))
+        for e in w.engines:
+            e.close()
+    assert len(played[0]) >= 64 and played[0] == played[1]
     with pytest.raises(ValueError):
         SelfPlayWorker(_config({'module': 'alphazero.games.connectfour', 'name': 'ConnectFour'},
                                {'module': 'alphazero.games.connectfour', 'name': 'AlphaZeroC4',
