@@ -27,7 +27,6 @@
 #define EPT 3                  // elements of a board tensor [42][32] per thread of a conv step: element tid + 512 j is
                                // (cell = group + 16 j, channel = tid & 31) -- the same cells the thread computes
 
-
 // The thread's index as a value the compiler has to take as new each time: in the one-launch pass the steps sit in
 // loops, and everything a step derives from the thread index (LDS addresses, cell numbers, masks) would otherwise be
 // computed once in front of the loops and kept in registers for the whole kernel -- some hundreds of them.
@@ -81,13 +80,10 @@ struct ChainExchange {
 // Inside one launch: a row is 64 pairs (value, tag) of eight bytes, stored and loaded as single agent-scope accesses.
 // A pair is valid as soon as its tag is the expected one, so neither side needs a fence or a counter; consecutive
 // steps use two row sets in turn (a workgroup can be at most one step ahead of the slowest one, because it needs
-// every workgroup's row of the step before).  A reader gives up after POLL_LIMIT rounds of polling (about a second) or
-// as soon as another workgroup has: the launch then ends with an error instead of hanging.
+// every workgroup's row of the step before).  A reader gives up after POLL_LIMIT rounds of polling (0.4 s to a second)
+// or as soon as another workgroup has: the launch then ends with an error instead of hanging.
 #define POLL_LIMIT (1 << 20)
-#ifndef POLL_SLOTS
-#define POLL_SLOTS 16
-#endif
-//         // pairs a thread has in flight
+#define POLL_SLOTS 16         // pairs a thread has in flight per round of polling
 #ifdef PASS_TIMING
 #define STEP_MARK(ex, i) do { if ((ex).marks() && blockIdx.x == 0 && threadIdx.x == 0) (ex).marks()[i] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
