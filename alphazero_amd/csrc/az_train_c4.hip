@@ -92,8 +92,10 @@ Ws layout(int boards, int blocks) {
 __global__ void __launch_bounds__(TT)
 k_train_prep(const float* __restrict__ c1, const float* __restrict__ c2, const float* __restrict__ stem, float* __restrict__ wf1,
              float* __restrict__ wb1, float* __restrict__ wf2, float* __restrict__ wb2, float* __restrict__ ws,
-             float* __restrict__ bn_acc /* [3][64] */, int* __restrict__ ctl) {
+             float* __restrict__ bn_acc /* [3][64] */, int* __restrict__ ctl, unsigned long long* __restrict__ rows, int num_rows) {
     const int i = blockIdx.x * TT + threadIdx.x;
+    // the one-launch form's rows start every pass without a valid tag, whatever the workspace held before
+    for (int j = i; j < num_rows * 64; j += (int)gridDim.x * TT) rows[j] = 0ull;
     if (i < 9 * TC * TC) {
         // (within a row the two halves of 16 change places when the row's index is odd: the four rows that one matrix
         // instruction's operand is read from then lie in different LDS banks, conv_mfma)
@@ -250,7 +252,7 @@ __device__ __forceinline__ bool pass_steps(const PassArgs& A, float* lds, double
     float* red = lds + CONV_LDS_RED;
     int* ctl = reinterpret_cast<int*>(W + w.ctl);
     unsigned long long* rows = reinterpret_cast<unsigned long long*>(W + w.rows);
-    const uint32_t tag0 = ((uint32_t)(ctl[0] & 0xFFFFF) + 1u) << 8;          // never 0: a fresh workspace matches no step
+    const uint32_t tag0 = ((uint32_t)(ctl[0] & 0xFFFFF) + 1u) << 8;          // never 0: a cleared row matches no step
     // step p adds up the rows tagged p (set p & 1) and posts rows tagged p + 1 (the other set)
 #ifdef PASS_TIMING
     // workgroup 0 notes the time at which each step's sums were complete (2 p) and at which the step ended (2 p + 1)
@@ -486,9 +488,10 @@ int check_args(const az_c4_train_net* net, const float* x, const uint8_t* valid,
     }
     return 0;
 }
-int launch_prep(const az_c4_train_net* net, float* W, const Ws& w, hipStream_t st) {
+int launch_prep(const az_c4_train_net* net, float* W, const Ws& w, int boards, hipStream_t st) {
     hipLaunchKernelGGL(k_train_prep, dim3((9 * TC * TC + TT - 1) / TT), dim3(TT), 0, st, net->c1_w, net->c2_w, net->stem_w,
-                       W + w.wf1, W + w.wb1, W + w.wf2, W + w.wb2, W + w.ws, W + w.bn_acc, reinterpret_cast<int*>(W + w.ctl));
+                       W + w.wf1, W + w.wb1, W + w.wf2, W + w.wb2, W + w.ws, W + w.bn_acc, reinterpret_cast<int*>(W + w.ctl),
+                       reinterpret_cast<unsigned long long*>(W + w.rows), 2 * boards);
     AZ_LAUNCH_CHECK("k_train_prep");
     return 0;
 }
@@ -550,7 +553,7 @@ int az_c4_train_fwd_bwd_chain(const az_c4_train_net* net, const float* x, const 
 
     const float* nof = nullptr;
     // ---- forward
-    if (int rc = launch_prep(net, W, w, st)) return rc;
+    if (int rc = launch_prep(net, W, w, B, st)) return rc;
     hipLaunchKernelGGL(k_train_stem_fwd, dim3(B), dim3(TT), 0, st, x, W + w.ws, Zl(0), Pout());
     next();
     for (int k = 0; k < nb; ++k) {
@@ -683,7 +686,7 @@ int az_c4_train_fwd_bwd(const az_c4_train_net* net, const float* x, const uint8_
         AZ_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_train_pass), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         if (dev < 64) lds_set[dev].store(lds_bytes, std::memory_order_release);
     }
-    if (int rc = launch_prep(net, W, a.w, st)) return rc;
+    if (int rc = launch_prep(net, W, a.w, batch, st)) return rc;
     hipLaunchKernelGGL(k_train_pass, dim3(batch), dim3(TTC), lds_bytes, st, a);
     AZ_LAUNCH_CHECK("k_train_pass");
     return 0;

@@ -291,7 +291,7 @@ typedef struct az_c4_train_net {
     const float* val_fc2_b; float* val_fc2_b_grad;       /* [1] */
 } az_c4_train_net;
 /* bytes of DEVICE workspace az_c4_train_fwd_bwd needs for this batch size and depth (contents need not be kept
- * between calls)                                                                                              */
+ * between calls and need no initialisation)                                                                   */
 long az_c4_train_workspace_bytes(int32_t batch, int32_t num_blocks);
 /* x float [batch][2][6][7] (ConnectFour.render planes), valid uint8 [batch][7], target_p float [batch][7], z float
  * [batch]; out3 DEVICE float[3] = {policy loss, value loss, max |sum(target) - 1|} as az_loss_fwd_bwd;

@@ -404,6 +404,13 @@ def test_one_launch_training_pass_over_many_launches_and_the_wrap_of_its_launch_
     assert int(ctl[0]) == 0xFFFFF + 20
     for a, b in zip(one.parameters(), grads):
         assert torch.equal(a.grad, b)
+    # the workspace needs no initialisation: whatever it holds (stale rows, a set error word), a pass gives the same
+    for it in range(3):
+        s_one._ws.random_(0, 256)
+        got = s_one.run(x, p, z, valid)
+        assert torch.equal(got, want), (it, got, want)
+    for a, b in zip(one.parameters(), grads):
+        assert torch.equal(a.grad, b)
 
 
 def test_one_launch_training_pass_gives_up_when_a_workgroup_does_not_arrive():
