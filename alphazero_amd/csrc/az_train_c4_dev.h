@@ -200,6 +200,23 @@ __device__ __forceinline__ void bn_scale_shift(const float* st, const float* gam
     }
 }
 
+// both of the above for a 32-channel batch-norm whose statistics are being made, by the same 32 threads, one barrier
+__device__ __forceinline__ void stats_scale_shift(const double* tot, long n, float eps, const BnRef& bn, float* sc, float* sh) {
+    if (threadIdx.x < TC) {
+        const int c = threadIdx.x;
+        const double mean = tot[c] / (double)n;
+        double var = tot[32 + c] / (double)n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float m = (float)mean, inv = (float)(1.0 / sqrt(var + (double)eps)), v = (float)var;
+        bn.st[c] = m; bn.st[32 + c] = inv; bn.st[64 + c] = v;
+        if (blockIdx.x == 0) { bn.stat_keep[c] = m; bn.stat_keep[32 + c] = inv; bn.stat_keep[64 + c] = v; }
+        const float k = bn.gamma[c] * inv;
+        sc[c] = k;
+        sh[c] = bn.beta[c] - m * k;
+    }
+    __syncthreads();
+}
+
 // The 3x3 conv of one board on the fp32 matrix instruction v_mfma_f32_16x16x4_f32 (D[16 out][16 cells] += W[out][4 k]
 // X[4 k][cells]): the board is three tiles of 16 cells (42 of 48 exist; 32-wide tiles would carry 64), the output two
 // halves of 16 channels.  Waves 0..5 take one (channel half, cell tile) each through taps 0..6, waves 6 and 7 the
@@ -456,11 +473,9 @@ __device__ __forceinline__ bool conv_fwd_step(const float* zin, BnRef bn, const 
     }
     const WRegs wr = load_conv_weights(wf);
     for (int i = tid; i < PADCELLS * TS; i += TTC) tile[i] = 0.0f;
+    store_conv_weights(wl, wr);                        // (while the rows are on their way)
     if (ex.template gather<TTC / 64>(tot, scratch)) return true;
-    store_conv_weights(wl, wr);
-    stats_from_totals(tot, TC, (long)boards * CELLS, eps, bn.st, bn.stat_keep);
-    bn_scale_shift(bn.st, bn.gamma, bn.beta, sc, sh);
-    __syncthreads();
+    stats_scale_shift(tot, (long)boards * CELLS, eps, bn, sc, sh);
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
         const int i = tid + j * TTC;
@@ -501,9 +516,7 @@ __device__ __forceinline__ bool head_conv_fwd_step(const float* zin, BnRef bn, c
     if (tid < 2 * TC) wh[tid] = wp[tid];
     if (tid < TC) wh[2 * TC + tid] = wv[tid];
     if (ex.template gather<TT / 64>(tot, scratch)) return true;
-    stats_from_totals(tot, TC, (long)boards * CELLS, eps, bn.st, bn.stat_keep);
-    bn_scale_shift(bn.st, bn.gamma, bn.beta, sc, sh);
-    __syncthreads();
+    stats_scale_shift(tot, (long)boards * CELLS, eps, bn, sc, sh);
     if (on)
         for (int i = tid; i < CELLS * TC; i += TT) {
             const int cell = i >> 5, c = i & 31;
@@ -883,12 +896,12 @@ __device__ __forceinline__ bool conv_bwd_step(bool accum, const float* dyout, co
     const WgOld wold = wgrad_load_old(accum, pw + (size_t)b * 9 * TC * TC, tid >> 6, tid & 63);
     const float sp_mean = stat_prev[lane32], sp_inv = stat_prev[32 + lane32];
     for (int i = tid; i < 2 * PADCELLS * TS; i += TTC) dzt[i] = 0.0f;         // both tiles
+    store_conv_weights(wl, wr);                        // (while the rows are on their way)
+    if (MODE_T) bn_scale_shift(stat_in, gamma_in, beta_in, sc, sh);
     if (ex.template gather<TTC / 64>(tot, scratch)) return true;
     STEP_MARK(ex, 0);
-    store_conv_weights(wl, wr);
     bn_back_coeff(ob, tot, TC, inv_n, k1, m1, m2, mean, invstd);
     accumulate_bn_grad(tot, bn_acc_out);
-    if (MODE_T) bn_scale_shift(stat_in, gamma_in, beta_in, sc, sh);
     __syncthreads();
     float a_own[EPT];
 #pragma unroll
