@@ -239,7 +239,7 @@ __device__ __forceinline__ void conv_mfma(const float* tile, const float* w, flo
         f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc0;
         const float* wbase = w + kq * TC + ((ot * 16 + col) ^ ((kq & 1) * 16));
         const float* xbase = tile + pi * TS + kq;
-#pragma unroll 1
+#pragma unroll
         for (int t = 0; t < 6; t += 2) {
             const float* x0 = xbase + SIGN * tap_offset(t) * TS;
             const float* x1 = xbase + SIGN * tap_offset(t + 1) * TS;
