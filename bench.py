@@ -179,6 +179,56 @@ def latest_profile(name_suffix):
     return files[-1] if files else None
 
 
+def live_counter_passes(args):
+    """FETCH_SIZE and WRITE_SIZE of this command's kernels, measured now: this script run twice as a child process
+    under rocprofv3 --pmc (one counter per pass, no tracing), a few steps each.  Returns {counter: {kernel name: mean
+    per launch}} or None when the profiler is missing or a pass fails (the committed passes are used then)."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(prof):
+        return None
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['TMPDIR'] = '/tmp'
+    res = {}
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        d = tempfile.mkdtemp(prefix='az_pmc_', dir='/tmp')
+        cmd = [prof, '--pmc', counter, '--output-format', 'csv', '-d', d, '--', sys.executable, os.path.join(ROOT, 'bench.py'),
+               '--no-cpu-baseline', '--no-extras', '--steps', '2', '--warmup', '1', '--preroll', '8', '--games', str(args.games),
+               '--sims', str(args.sims), '--mix-moves', str(args.mix_moves), '--model', args.model, '--net-impl', args.net_impl]
+        if args.stepwise:
+            cmd.append('--stepwise')
+        try:
+            child = subprocess.Popen(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                     start_new_session=True)
+            try:
+                rc = child.wait(timeout=240)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(child.pid, signal.SIGKILL)        # the profiler and the run under it: this group only
+                child.wait()
+                return None
+            if rc != 0:
+                return None
+            agg = collections.defaultdict(list)
+            for f in glob.glob(os.path.join(d, '*', '*counter_collection.csv')):
+                for row in csv.DictReader(open(f)):
+                    if row['Counter_Name'] == counter:
+                        agg[row['Kernel_Name']].append(float(row['Counter_Value']))
+            if not agg:
+                return None
+            res[counter] = {k: sum(v) / len(v) for k, v in agg.items()}
+        except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return res
+
+
 def measure_agreement(dev, side_a, side_b, S, note, games=256, moves=12, seed=77):
     """Two evaluators in the same self-play (alphazero/mcts.py:94-107 evaluates in fp32): `games` Connect Four
     games from the empty board on identical Dirichlet / sampling streams (same engine seed: the device RNG is
@@ -424,6 +474,9 @@ def main():
                          'default for the <= 32-channel HIP network up to 16384 games')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--no-live-traffic', action='store_true',
+                    help='take roofline.traffic from the newest committed profiles/rNN_pmc_means.json instead of measuring it '
+                         'now (two child runs of this command under rocprofv3 --pmc)')
     ap.add_argument('--no-extras', action='store_true',
                     help='skip the extra measurements of the N = 1 line, made after the timed region (fp32 network, agreement, '
                          'BASELINE configs 2, 4 and 5)')
@@ -644,15 +697,29 @@ def main():
         def avg_ms(pairs):
             return sum(a.elapsed_time(b) for a, b in pairs) / len(pairs)
 
+        # HBM traffic of the kernels of this command: measured now when this is the plain one-GPU line (two child runs
+        # under rocprofv3 --pmc, FETCH_SIZE and WRITE_SIZE in passes of their own), else from the committed passes
+        live = None
+        if not multi and not args.no_extras and not args.no_live_traffic and net is not None and args.net_impl == 'hip':
+            live = live_counter_passes(args)
+        out['traffic_source'] = ('two rocprofv3 --pmc passes of this command (FETCH_SIZE, WRITE_SIZE), run by bench.py after the '
+                                 'timed region' if live else
+                                 'newest committed profiles/rNN_pmc_means.json (counter passes of this command)')
+
         def pmc_traffic(*kernel_prefixes):
-            """HBM bytes per launch from the newest committed counter passes of this same command
-            (profiles/rNN_pmc_means.json: FETCH_SIZE and WRITE_SIZE in KiB, separate passes;
-            FETCH_SIZE doubled, the gfx950 correction for 16-byte-per-lane reads).  A kernel is named by the
-            start of its signature, with or without the leading return type."""
+            """HBM bytes per launch from counter passes of this same command (FETCH_SIZE and WRITE_SIZE in KiB,
+            separate passes; FETCH_SIZE doubled, the gfx950 correction for 16-byte-per-lane reads): the live
+            passes when there are any, else profiles/rNN_pmc_means.json.  A kernel is named by the start of its
+            signature, with or without the leading return type."""
             def named(k):
                 k = k[5:] if k.startswith('void ') else k
                 return any(k.startswith(p[5:] if p.startswith('void ') else p) for p in kernel_prefixes)
             try:
+                if live:
+                    fe = [v for k, v in live['FETCH_SIZE'].items() if named(k)]
+                    wr = [v for k, v in live['WRITE_SIZE'].items() if named(k)]
+                    if fe and wr:
+                        return (2.0 * fe[0] + wr[0]) * 1024.0
                 pm = json.load(open(latest_profile('pmc_means.json')))
                 for fk, wk in (('pmc_fetch', 'pmc_write'), ('pmc_stepwise_fetch', 'pmc_stepwise_write')):
                     fe = [v['FETCH_SIZE']['mean'] for k, v in pm.get(fk, {}).items() if named(k)]
