@@ -206,7 +206,7 @@ def live_counter_passes(args):
             child = subprocess.Popen(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                                      start_new_session=True)
             try:
-                rc = child.wait(timeout=240)
+                rc = child.wait(timeout=90)
             except subprocess.TimeoutExpired:
                 import signal
                 os.killpg(child.pid, signal.SIGKILL)        # the profiler and the run under it: this group only
