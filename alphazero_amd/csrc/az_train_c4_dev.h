@@ -628,7 +628,7 @@ __device__ __forceinline__ void head_fc_bwd_step(const float* x, const float* dl
                                                  const float* wpf, const float* w1, const float* w2, float* dh1, float* dpre2, float* dcl,
                                                  float* dyh, const EX& ex, float* d1 /* LDS [256] */, float* dcl_s /* LDS [42] */,
                                                  int* height /* LDS [8] */, float* red /* LDS [512 + 256] */, float* w1_l /* LDS [256][42] */,
-                                                 bool w1_staged) {
+                                                 bool w1_staged /* w1_l and height are in place */) {
     const int b = blockIdx.x, tid = step_tid();
     const bool on = tid < TT;
     float* vpart = red + 512;                          // [6][42]
@@ -642,7 +642,7 @@ __device__ __forceinline__ void head_fc_bwd_step(const float* x, const float* dl
     }
     if (tid == 0) dpre2[b] = dp;
     if (tid < CELLS) dcl_s[tid] = 0.0f;
-    if (tid >= 128 && tid < 135) {
+    if (!w1_staged && tid >= 128 && tid < 135) {       // (staged: the forward part of this step has left the heights too)
         const int col = tid - 128;
         float n = 0.0f;
         for (int k = 0; k < 12; ++k) n += x[(size_t)b * 84 + k * 7 + col];
@@ -958,19 +958,34 @@ __device__ __forceinline__ bool stem_bwd_step(const float* x, const float* dy0, 
     const int b = blockIdx.x, tid = step_tid(), co = tid & 31, g = tid >> 5;
     const bool on = tid < TT;
     const float inv_n = 1.0f / (float)((long)boards * CELLS);
+    // every global load of the step before the wait for the rows
+    float zr[NPOS], dr[NPOS];
+    float xv = 0.0f;
+    if (on) {
+#pragma unroll
+        for (int j = 0; j < NPOS; ++j) {
+            const int i = tid + j * TT;
+            const size_t gi = (size_t)b * CELLS * TC + i;
+            zr[j] = i < CELLS * TC ? z0[gi] : 0.0f;
+            dr[j] = i < CELLS * TC ? dy0[gi] : 0.0f;
+        }
+        if (tid < 2 * CELLS) xv = x[(size_t)b * 84 + tid];
+        for (int i = tid; i < PADCELLS * 2; i += TT) xt[i] = 0.0f;
+    }
     if (ex.template gather<TT / 64>(tot, scratch)) return true;
     bn_back_coeff(ob, tot, TC, inv_n, k1, m1, m2, mean, invstd);
     accumulate_bn_grad(tot, bn_acc_out);
-    if (on)
-        for (int i = tid; i < PADCELLS * 2; i += TT) xt[i] = 0.0f;
     __syncthreads();
     if (on) {
-        for (int i = tid; i < 2 * CELLS; i += TT) xt[pad_index(i % CELLS) * 2 + i / CELLS] = x[(size_t)b * 84 + i];
-        for (int i = tid; i < CELLS * TC; i += TT) {
-            const int c = i & 31;
-            const size_t gi = (size_t)b * CELLS * TC + i;
-            const float xh = (z0[gi] - mean[c]) * invstd[c];
-            dzt[i] = k1[c] * (dy0[gi] - m1[c] - xh * m2[c]);
+        if (tid < 2 * CELLS) xt[pad_index(tid % CELLS) * 2 + tid / CELLS] = xv;
+#pragma unroll
+        for (int j = 0; j < NPOS; ++j) {
+            const int i = tid + j * TT;
+            if (i < CELLS * TC) {
+                const int c = i & 31;
+                const float xh = (zr[j] - mean[c]) * invstd[c];
+                dzt[i] = k1[c] * (dr[j] - m1[c] - xh * m2[c]);
+            }
         }
     }
     __syncthreads();
