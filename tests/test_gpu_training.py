@@ -334,7 +334,7 @@ def _c4_batch(B, seed, rng):
     return x, p, z, valid
 
 
-@pytest.mark.parametrize('blocks,B', [(6, 128), (1, 16), (0, 8), (2, 77), (3, 256), (6, 2)])
+@pytest.mark.parametrize('blocks,B', [(6, 128), (1, 16), (0, 8), (2, 77), (3, 256), (6, 2), (14, 40)])
 def test_one_launch_training_pass_equals_the_chain_of_launches(blocks, B):
     """The two forms of az_c4_train_fwd_bwd run the same steps with the same thread-to-data mapping and differ only in
     how the boards' partial sums travel between steps (tagged pairs polled inside one resident grid / rows read after
